@@ -1,0 +1,227 @@
+"""Deterministic synthetic corpora for the BASELINE.json configs.
+
+Text is drawn by a unigram sampler over the bundled vocab.txt `(token, count)`
+lines: a sampled `xx@@` piece is glued to the next piece, any other piece ends a
+word; words are joined by one space.  Everything is numpy-vectorised so that the
+1 M-document config builds in seconds; the stream is fully determined by
+`(seed, word-count plan)` and numpy's PCG64.
+
+Used by bench.py, the GPU parity tests and tests/golden/make_golden.py.  It
+reads only the data files shipped in this repository.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from typing import Optional, Tuple
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+DATA_DIR = os.path.join(_HERE, "genz-tokenize_amd", "genz_tokenize", "data")
+VOCAB_PATH = os.path.join(DATA_DIR, "vocab.txt")
+BPE_PATH = os.path.join(DATA_DIR, "bpe.codes")
+
+
+def _fill(out, dst, flat, src, lens):
+    """out[dst[i]:dst[i]+lens[i]] = flat[src[i]:src[i]+lens[i]] for every i."""
+    lib = _fill_lib()
+    dst = np.ascontiguousarray(dst, dtype=np.int64)
+    src = np.ascontiguousarray(src, dtype=np.int64)
+    lens = np.ascontiguousarray(lens, dtype=np.int64)
+    if lib is not None:
+        P = ctypes.c_void_p
+        lib.corpus_fill(P(out.ctypes.data), P(dst.ctypes.data), P(flat.ctypes.data),
+                        P(src.ctypes.data), P(lens.ctypes.data), ctypes.c_int64(len(lens)))
+        return
+    # same bytes without the helper (slow: builds per-byte index arrays)
+    nb = int(lens.sum())
+    piece_of = np.repeat(np.arange(len(lens)), lens)
+    within = np.arange(nb) - np.repeat(np.cumsum(lens) - lens, lens)
+    out[dst[piece_of] + within] = flat[src[piece_of] + within]
+
+
+_LIB = []
+
+
+def _fill_lib():
+    if not _LIB:
+        path = os.path.join(_HERE, "tools", "corpus_fill.so")
+        _LIB.append(ctypes.CDLL(path) if os.path.exists(path) else None)
+    return _LIB[0]
+
+
+class Sampler:
+    def __init__(self, vocab_path: str = VOCAB_PATH):
+        toks, counts = [], []
+        with open(vocab_path, "rb") as f:
+            for line in f.read().split(b"\n"):
+                if not line:
+                    continue
+                w, c = line.rsplit(b" ", 1)
+                toks.append(w); counts.append(int(c))
+        cont = np.array([t.endswith(b"@@") for t in toks])
+        body = [t[:-2] if c else t for t, c in zip(toks, cont)]
+        self.lens = np.array([len(b) for b in body], dtype=np.int64)
+        self.starts = np.concatenate([[0], np.cumsum(self.lens)[:-1]]).astype(np.int64)
+        self.flat = np.frombuffer(b"".join(body), dtype=np.uint8)
+        self.cont = cont
+        cum = np.cumsum(np.array(counts, dtype=np.float64))
+        # quantile table: piece = qtab[uniform 22-bit integer]
+        q = (np.arange(1 << 22, dtype=np.float64) + 0.5) * (cum[-1] / (1 << 22))
+        self.qtab = np.minimum(np.searchsorted(cum, q, side="right"), len(cum) - 1).astype(np.int32)
+
+    def docs(self, rng: np.random.Generator, words_per_doc: np.ndarray
+             ) -> Tuple[np.ndarray, np.ndarray]:
+        """Return (packed uint8 text, int64 offsets[N+1]) for documents with the
+        given word counts (each >= 1)."""
+        n_words = int(words_per_doc.sum())
+        pieces = []
+        have = 0
+        # over-sample pieces until the stream holds n_words word-final pieces
+        while have < n_words:
+            m = int((n_words - have) * 1.05) + 64
+            p = self.qtab[rng.integers(0, 1 << 22, size=m, dtype=np.int32)]
+            pieces.append(p)
+            have += int((~self.cont[p]).sum())
+        p = np.concatenate(pieces)
+        final = ~self.cont[p]
+        word_no = np.cumsum(final)                       # 1-based index of the word a final piece closes
+        last = int(np.searchsorted(word_no, n_words, side="left"))
+        p, final = p[:last + 1], final[:last + 1]
+        doc_end_word = np.cumsum(words_per_doc)          # word index (1-based) closing each doc
+        final_pos = np.flatnonzero(final)                # piece index of each word's last piece
+        doc_last_piece = final_pos[doc_end_word - 1]
+        # a space follows every word-final piece except a document's last one
+        space = final.copy()
+        space[doc_last_piece] = False
+        plen = self.lens[p] + space
+        dst = np.concatenate([[0], np.cumsum(plen)]).astype(np.int64)
+        total = int(dst[-1])
+        out = np.full(total, 0x20, dtype=np.uint8)
+        body_len = self.lens[p]
+        src0 = self.starts[p]
+        _fill(out, dst[:-1], self.flat, src0, body_len)
+        offsets = np.concatenate([[0], dst[doc_last_piece + 1]]).astype(np.int64)
+        return out, offsets
+
+
+def plan_short(rng, n):           # cfg 2: words/sentence ~ U[5,30]
+    return rng.integers(5, 31, size=n)
+
+
+def plan_mixed(rng, n):           # cfg 3/4: 70 % U[5,30], 25 % U[31,120], 5 % U[121,400]
+    u = rng.random(n)
+    a = rng.integers(5, 31, size=n)
+    b = rng.integers(31, 121, size=n)
+    c = rng.integers(121, 401, size=n)
+    return np.where(u < 0.70, a, np.where(u < 0.95, b, c))
+
+
+_NOISE = ("0123456789_-.,;:!?()[]{}<>/\\@#$%^&*+=~`'\"|"
+          "ABCDEFGHIJKLMNOPQRSTUVWXYZqwzjf"
+          "ÀÁÂÃÈÉÊÌÍÒÓÔÕÙÚÝàáâãèéêìíòóôõùúýĂăĐđĨĩŨũƠơƯưẠạẢảẤấẦầẨẩẪẫẬậẮắẰằẲẳẴẵẶặẸẹẺẻẼẽẾếỀềỂểỄễỆệỈỉỊịỌọỎỏỐốỒồỔổỖỗỘộỚớỜờỞởỠỡỢợỤụỦủỨứỪừỬửỮữỰựỲỳỴỵỶỷỸỹ"
+          "😀🙂🚀中文字кириллицаαβγ€™…–—“”")
+_GAPS = [" ", " ", " ", "  ", "\t", "\n", "\n\n", "\r\n", " ", " ", "　", " \n ", "\x1c", " "]
+
+
+def add_noise(text: np.ndarray, offsets: np.ndarray, seed: int, rate: float = 0.03
+              ) -> Tuple[np.ndarray, np.ndarray]:
+    """Rewrite a corpus document by document, replacing ~rate of the words with
+    random junk (mixed scripts, emoji, long runs, literal '@@' and '</w>') and
+    ~rate of the single spaces with other Unicode whitespace.  Python-speed; use
+    on parity-test sized corpora only."""
+    import random
+    r = random.Random(seed)
+    docs, offs = [], [0]
+    raw = text.tobytes()
+    for i in range(len(offsets) - 1):
+        words = raw[offsets[i]:offsets[i + 1]].decode("utf-8").split(" ")
+        parts = []
+        for w in words:
+            x = r.random()
+            if x < rate:
+                k = r.choice([1, 1, 2, 3, 5, 8, 13, 21, 40, 70, 150])
+                w = "".join(r.choice(_NOISE) for _ in range(k))
+            elif x < rate * 1.3:
+                w = w + r.choice(["@@", "</w>", "</w>x", "@@ x", w, w + w])
+            parts.append(w)
+            parts.append(r.choice(_GAPS) if r.random() < rate else " ")
+        if r.random() < 0.5:
+            parts.pop()
+        if r.random() < 0.02:
+            parts = []
+        b = "".join(parts).encode("utf-8")
+        docs.append(b); offs.append(offs[-1] + len(b))
+    return np.frombuffer(b"".join(docs), dtype=np.uint8).copy(), np.array(offs, dtype=np.int64)
+
+
+def config_corpus(cfg: int, n_docs: Optional[int] = None, seed: Optional[int] = None,
+                  sampler: Optional[Sampler] = None):
+    """(text, offsets, max_len) for BASELINE.json configs 2, 3, 4 (per shard) and 5."""
+    s = sampler or Sampler()
+    if cfg == 2:
+        n, seed, L = n_docs or 10_000, 1234 if seed is None else seed, 128
+        rng = np.random.Generator(np.random.PCG64(seed))
+        t, o = s.docs(rng, plan_short(rng, n))
+    elif cfg in (3, 4):
+        n, seed, L = n_docs or 1_000_000, 3 if seed is None else seed, 256
+        rng = np.random.Generator(np.random.PCG64(seed))
+        t, o = s.docs(rng, plan_mixed(rng, n))
+    elif cfg == 5:
+        n, seed, L = n_docs or 50_000, 5 if seed is None else seed, 1024
+        rng = np.random.Generator(np.random.PCG64(seed))
+        t, o = s.docs(rng, np.full(n, 900))
+        t, o = _cut_chars(t, o, 4000)
+    else:
+        raise ValueError(cfg)
+    return t, o, L
+
+
+def _cut_chars(text, offsets, max_chars):
+    """Cut every document to its first `max_chars` code points, then strip."""
+    lead = (text & 0xC0) != 0x80
+    cs = np.concatenate([[0], np.cumsum(lead)])
+    docs, offs = [], [0]
+    raw = text
+    for i in range(len(offsets) - 1):
+        a, b = int(offsets[i]), int(offsets[i + 1])
+        want = cs[a] + max_chars
+        e = int(np.searchsorted(cs, want, side="right")) - 1 if cs[b] - cs[a] > max_chars else b
+        e = min(e, b)
+        while e > a and raw[e - 1] == 0x20:
+            e -= 1
+        docs.append(raw[a:e]); offs.append(offs[-1] + (e - a))
+    return np.concatenate(docs), np.array(offs, dtype=np.int64)
+
+
+def custom_tables(seed: int = 5, n_vocab: int = 100_000,
+                  vocab_path: str = VOCAB_PATH, bpe_path: str = BPE_PATH):
+    """cfg 5 tables: merges = bundled merges WITHOUT the '#version' header line
+    (real merges become ranks 0..); vocab = every token form the merges or the
+    bundled vocab can produce + seeded filler words, shuffled (ids differ from
+    the bundled ones).  Returns (vocab_bytes, bpe_bytes)."""
+    import random
+    bpe = open(bpe_path, "rb").read().decode("utf-8")
+    lines = bpe.split("\n")
+    body = [l for l in lines[1:] if l]
+    forms = []
+    seen = set()
+
+    def add(form):
+        if form not in seen:
+            seen.add(form); forms.append(form)
+    for line in open(vocab_path, "rb").read().decode("utf-8").split("\n"):
+        if line:
+            add(line[:line.rfind(" ")])
+    for l in body:
+        a, b = l.split(" ")
+        for s in (a, b, a + b):
+            add(s[:-4] if s.endswith("</w>") else s + "@@")
+    r = random.Random(seed)
+    k = 0
+    while len(forms) < n_vocab:
+        add("zq%dx%d" % (k, r.randrange(10 ** 6))); k += 1
+    r.shuffle(forms)
+    vocab = "".join("%s %d\n" % (f, 1 + (i * 7919) % 1000) for i, f in enumerate(forms))
+    return vocab.encode("utf-8"), ("\n".join(body) + "\n").encode("utf-8")

@@ -1,0 +1,714 @@
+// S1 -- the C ABI (include/genz_tokenize.h): context, device tables, workspace, launches, RCCL gather.
+// No C++ exception leaves this file; there is no CPU fallback for any entry point that computes.
+#include "../../include/genz_tokenize.h"
+#include "gz_kernels.h"
+
+#include <dlfcn.h>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+
+namespace {
+
+thread_local std::string g_create_err;
+
+struct DBuf {                       // grow-only device buffer
+    void* p = nullptr;
+    size_t cap = 0;
+};
+
+// ---- RCCL through dlopen (the library loads on machines without RCCL or without a GPU) -----------------------
+struct Id128 { char b[128]; };      // ncclUniqueId
+struct Rccl {
+    void* h = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, Id128 /* ncclUniqueId by value */, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+std::once_flag g_rccl_once;
+
+bool rccl_load()
+{
+    std::call_once(g_rccl_once, [] {
+        void* h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+        if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
+        if (!h) return;
+        g_rccl.h = h;
+        g_rccl.GetUniqueId = (int (*)(void*))dlsym(h, "ncclGetUniqueId");
+        g_rccl.CommInitRank = (int (*)(void**, int, Id128, int))dlsym(h, "ncclCommInitRank");
+        g_rccl.CommDestroy = (int (*)(void*))dlsym(h, "ncclCommDestroy");
+        g_rccl.GroupStart = (int (*)())dlsym(h, "ncclGroupStart");
+        g_rccl.GroupEnd = (int (*)())dlsym(h, "ncclGroupEnd");
+        g_rccl.Send = (int (*)(const void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclSend");
+        g_rccl.Recv = (int (*)(void*, size_t, int, int, void*, hipStream_t))dlsym(h, "ncclRecv");
+        g_rccl.GetErrorString = (const char* (*)(int))dlsym(h, "ncclGetErrorString");
+    });
+    return g_rccl.h && g_rccl.GetUniqueId && g_rccl.CommInitRank && g_rccl.Send && g_rccl.Recv &&
+           g_rccl.GroupStart && g_rccl.GroupEnd;
+}
+
+}  // namespace
+
+struct gz_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::mutex mu;
+
+    bool have_tables = false;
+    GzHostTables host;
+    GzDeviceTables dev{};
+    DBuf t_pair, t_merges, t_symids, t_bmp, t_astral;
+
+    // workspace
+    DBuf w_text, w_toff, w_pair, w_poff, w_ids, w_mask, w_tt, w_seq, w_rowoff, w_rowlen, w_pairlen, w_nreal,
+        w_status, w_raw, w_arena, w_flags, w_word, w_wordout;
+    int32_t* h_flags = nullptr;     // pinned: [0] defer, [1] capacity error, [2] bpe_word count
+
+    // the enqueued call (for gz_sync's arena pass)
+    struct Pending {
+        bool active = false;
+        GzEncodeArgs A{};
+        bool ragged = false;
+        GzFinalizeArgs F{};
+        bool pair = false;
+        GzPairArgs P{};
+        bool timing = false;
+    } pend;
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    double timing[4] = {0, 0, 0, 0};
+
+    void* comm = nullptr;
+    int rank = 0, world = 1;
+};
+
+namespace {
+
+int fail(gz_ctx* c, int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_err = buf;
+    return code;
+}
+
+#define HIPCHK(c, call)                                                                              \
+    do {                                                                                             \
+        hipError_t e_ = (call);                                                                      \
+        if (e_ != hipSuccess) return fail((c), GZ_E_HIP, "%s: %s", #call, hipGetErrorString(e_));    \
+    } while (0)
+
+int ensure(gz_ctx* c, DBuf& b, size_t bytes)
+{
+    if (bytes <= b.cap && b.p) return GZ_OK;
+    if (b.p) { hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    size_t want = bytes + 256;                      // slack: tile loads may touch up to 15 bytes past the text
+    want = (want + 4095) & ~(size_t)4095;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) { b.p = nullptr; return fail(c, GZ_E_NOMEM, "hipMalloc(%zu): %s", want, hipGetErrorString(e)); }
+    b.cap = want;
+    return GZ_OK;
+}
+
+void release(DBuf& b) { if (b.p) hipFree(b.p); b.p = nullptr; b.cap = 0; }
+
+template <class V>
+int upload(gz_ctx* c, DBuf& b, const V& v)
+{
+    size_t bytes = v.size() * sizeof(v[0]);
+    int rc = ensure(c, b, bytes ? bytes : 16);
+    if (rc) return rc;
+    if (bytes) HIPCHK(c, hipMemcpyAsync(b.p, v.data(), bytes, hipMemcpyHostToDevice, c->stream));
+    return GZ_OK;
+}
+
+bool is_dense(const GzShape& S) { return S.pad_mode && S.truncation && S.max_len >= 1; }
+
+GzShape make_shape(int32_t max_len, uint32_t flags)
+{
+    GzShape S;
+    S.max_len = max_len;
+    S.pad_mode = (!(flags & GZ_MAX_LEN_NONE) && (flags & GZ_PADDING)) ? 1 : 0;
+    S.truncation = (flags & GZ_TRUNCATION) ? 1 : 0;
+    return S;
+}
+
+// Enqueue every kernel of one call.  All pointers are device pointers.
+int enqueue(gz_ctx* c, bool huge_pass)
+{
+    gz_ctx::Pending& p = c->pend;
+    hipStream_t s = c->stream;
+    p.A.huge_pass = huge_pass ? 1 : 0;
+    p.A.arena = huge_pass ? (uint32_t*)c->w_arena.p : nullptr;
+    HIPCHK(c, hipMemsetAsync(c->w_flags.p, 0, 8, s));      // [0] defer, [1] capacity error
+    if (p.timing) HIPCHK(c, hipEventRecord(c->ev[0], s));
+    gz_launch_encode(c->dev, p.A, s);
+    if (p.timing) HIPCHK(c, hipEventRecord(c->ev[1], s));
+    if (p.ragged) {
+        gz_launch_rowscan(p.F, (int64_t*)c->w_rowlen.p, s);
+        gz_launch_finalize(c->dev, p.F, s);
+    }
+    if (p.timing) HIPCHK(c, hipEventRecord(c->ev[2], s));
+    if (p.pair) gz_launch_pair(c->dev, p.P, s);
+    if (p.timing) HIPCHK(c, hipEventRecord(c->ev[3], s));
+    HIPCHK(c, hipMemcpyAsync(c->h_flags, c->w_flags.p, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipGetLastError());
+    return GZ_OK;
+}
+
+int sync_locked(gz_ctx* c)
+{
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    gz_ctx::Pending& p = c->pend;
+    if (!p.active) return GZ_OK;
+    if (c->h_flags[0]) {
+        // some word exceeds the LDS long-word capacity: give the deferred documents a global arena
+        int64_t ends[2] = {0, 0}, begs[2] = {0, 0};
+        HIPCHK(c, hipMemcpy(&begs[0], p.A.text_off, 8, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(&ends[0], p.A.text_off + p.A.n_docs, 8, hipMemcpyDeviceToHost));
+        if (p.A.pair) {
+            HIPCHK(c, hipMemcpy(&begs[1], p.A.pair_off, 8, hipMemcpyDeviceToHost));
+            HIPCHK(c, hipMemcpy(&ends[1], p.A.pair_off + p.A.n_docs, 8, hipMemcpyDeviceToHost));
+        }
+        size_t total = (size_t)((ends[0] - begs[0]) + (ends[1] - begs[1]));
+        int rc = ensure(c, c->w_arena, total * 4 + 16);
+        if (rc) { p.active = false; return rc; }
+        rc = enqueue(c, true);
+        if (rc) { p.active = false; return rc; }
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+    }
+    if (p.timing) {
+        float ms = 0;
+        hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); c->timing[0] = ms;
+        hipEventElapsedTime(&ms, c->ev[1], c->ev[2]); c->timing[1] = ms;
+        hipEventElapsedTime(&ms, c->ev[2], c->ev[3]); c->timing[2] = ms;
+        hipEventElapsedTime(&ms, c->ev[0], c->ev[3]); c->timing[3] = ms;
+    }
+    p.active = false;
+    if (c->h_flags[1]) return fail(c, GZ_E_CAPACITY, "ragged output larger than capacity");
+    return GZ_OK;
+}
+
+int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off, const uint8_t* pair,
+                         const int64_t* pair_off, int64_t n_docs, int32_t max_len, uint32_t flags, int64_t capacity,
+                         int32_t* input_ids, int32_t* attention_mask, int32_t* token_type_ids, int32_t* sequence_id,
+                         int64_t* row_off, int32_t* pair_len, int32_t* n_real, int32_t* status,
+                         int64_t raw_elems /* < 0: unknown, read offsets from the device */)
+{
+    if (!c->have_tables) return fail(c, GZ_E_NOTABLES, "gz_load_tables has not been called");
+    if (n_docs < 0 || !text_off || (n_docs > 0 && !text)) return fail(c, GZ_E_INVALID, "bad text arguments");
+    if ((pair == nullptr) != (pair_off == nullptr)) return fail(c, GZ_E_INVALID, "pair and pair_off must both be given or both be NULL");
+    if (!input_ids || !attention_mask) return fail(c, GZ_E_INVALID, "input_ids / attention_mask are required");
+    const bool is_pair = pair_off != nullptr;
+    if (is_pair && (!token_type_ids || !sequence_id || !pair_len || !status))
+        return fail(c, GZ_E_INVALID, "pair mode needs token_type_ids, sequence_id, pair_len and status");
+    if (c->pend.active) { int rc = sync_locked(c); if (rc) return rc; }
+
+    const GzShape S = make_shape(max_len, flags);
+    const bool dense = is_dense(S);
+    if (dense && capacity < n_docs * (int64_t)max_len) return fail(c, GZ_E_CAPACITY, "capacity < n_docs*max_len");
+    if (!dense && !row_off) return fail(c, GZ_E_INVALID, "row_off is required for ragged layouts");
+
+    int rc;
+    if (!n_real) { rc = ensure(c, c->w_nreal, (size_t)(n_docs + 1) * 4); if (rc) return rc; n_real = (int32_t*)c->w_nreal.p; }
+    gz_ctx::Pending& p = c->pend;
+    p = gz_ctx::Pending();
+    p.timing = (flags & GZ_TIMING) != 0;
+    GzEncodeArgs& A = p.A;
+    A.text = text; A.text_off = text_off; A.pair = pair; A.pair_off = pair_off;
+    A.n_docs = n_docs; A.dense = dense ? 1 : 0; A.max_len = max_len;
+    A.ids = input_ids; A.mask = attention_mask; A.raw = nullptr; A.n_real = n_real;
+    A.defer_flag = (int32_t*)c->w_flags.p; A.arena = nullptr; A.huge_pass = 0;
+    if (!dense) {
+        if (raw_elems < 0) {
+            int64_t b[4] = {0, 0, 0, 0};
+            HIPCHK(c, hipMemcpy(&b[0], text_off, 8, hipMemcpyDeviceToHost));
+            HIPCHK(c, hipMemcpy(&b[1], text_off + n_docs, 8, hipMemcpyDeviceToHost));
+            if (is_pair) {
+                HIPCHK(c, hipMemcpy(&b[2], pair_off, 8, hipMemcpyDeviceToHost));
+                HIPCHK(c, hipMemcpy(&b[3], pair_off + n_docs, 8, hipMemcpyDeviceToHost));
+            }
+            raw_elems = (b[1] - b[0]) + (b[3] - b[2]) + (is_pair ? 4 : 2) * n_docs;
+        }
+        rc = ensure(c, c->w_raw, (size_t)raw_elems * 4 + 16); if (rc) return rc;
+        rc = ensure(c, c->w_rowlen, (size_t)(n_docs + 1) * 8); if (rc) return rc;
+        A.raw = (int32_t*)c->w_raw.p;
+        // raw token counts live in a private buffer: n_real is rewritten by the finalize kernel
+        rc = ensure(c, c->w_status, (size_t)(n_docs + 1) * 4); if (rc) return rc;
+        A.n_real = (int32_t*)c->w_status.p;
+        p.ragged = true;
+        GzFinalizeArgs& F = p.F;
+        F.text_off = text_off; F.pair_off = pair_off; F.n_docs = n_docs; F.S = S;
+        F.raw = A.raw; F.n_raw = A.n_real; F.row_off = row_off; F.capacity = capacity;
+        F.ids = input_ids; F.mask = attention_mask; F.n_real = n_real;
+        F.error_flag = (int32_t*)c->w_flags.p + 1;
+    }
+    if (is_pair) {
+        p.pair = true;
+        GzPairArgs& P = p.P;
+        P.n_docs = n_docs; P.S = S; P.row_off = dense ? nullptr : row_off; P.capacity = capacity;
+        P.ids = input_ids; P.seq = sequence_id; P.tt = token_type_ids; P.pair_len = pair_len; P.status = status;
+    }
+    p.active = true;
+    rc = enqueue(c, false);
+    if (rc) p.active = false;
+    return rc;
+}
+
+}  // namespace
+
+// =================================================================================================================
+extern "C" {
+
+int gz_version(void) { return GZ_VERSION; }
+
+int gz_create(int device_id, gz_ctx** out)
+{
+    if (!out) return GZ_E_INVALID;
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0)
+        return fail(nullptr, GZ_E_NODEVICE, "no HIP device (%s)", e == hipSuccess ? "count is 0" : hipGetErrorString(e));
+    if (device_id < 0 || device_id >= n) return fail(nullptr, GZ_E_INVALID, "device %d out of range (0..%d)", device_id, n - 1);
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device_id);
+    if (e != hipSuccess) return fail(nullptr, GZ_E_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, GZ_E_NODEVICE, "device %d is %s; this library is built for gfx950 only", device_id, prop.gcnArchName);
+    gz_ctx* c = new (std::nothrow) gz_ctx();
+    if (!c) return fail(nullptr, GZ_E_NOMEM, "out of host memory");
+    c->device = device_id;
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipHostMalloc((void**)&c->h_flags, 64, hipHostMallocDefault) != hipSuccess) {
+        delete c;
+        return fail(nullptr, GZ_E_HIP, "stream / pinned memory creation failed");
+    }
+    std::memset(c->h_flags, 0, 64);
+    for (auto& ev : c->ev) hipEventCreate(&ev);
+    if (ensure(c, c->w_flags, 64) != GZ_OK) { g_create_err = c->err; gz_destroy(c); return GZ_E_NOMEM; }
+    *out = c;
+    return GZ_OK;
+}
+
+void gz_destroy(gz_ctx* c)
+{
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    for (DBuf* b : {&c->t_pair, &c->t_merges, &c->t_symids, &c->t_bmp, &c->t_astral, &c->w_text, &c->w_toff, &c->w_pair,
+                    &c->w_poff, &c->w_ids, &c->w_mask, &c->w_tt, &c->w_seq, &c->w_rowoff, &c->w_rowlen, &c->w_pairlen,
+                    &c->w_nreal, &c->w_status, &c->w_raw, &c->w_arena, &c->w_flags, &c->w_word, &c->w_wordout})
+        release(*b);
+    for (auto& ev : c->ev) if (ev) hipEventDestroy(ev);
+    if (c->h_flags) hipHostFree(c->h_flags);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* gz_last_error(gz_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
+
+int gz_load_tables(gz_ctx* c, const uint8_t* vocab, size_t vocab_len, const uint8_t* bpe, size_t bpe_len,
+                   const char* const specials[5])
+{
+    if (!c || (!vocab && vocab_len) || (!bpe && bpe_len) || !specials) return c ? fail(c, GZ_E_INVALID, "bad arguments") : GZ_E_INVALID;
+    for (int i = 0; i < 5; ++i) if (!specials[i]) return fail(c, GZ_E_INVALID, "special token %d is NULL", i);
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->pend.active) { int rc = sync_locked(c); if (rc) return rc; }
+    c->have_tables = false;
+    int rc;
+    try {
+        static const uint8_t empty = 0;
+        rc = gz_build_tables(vocab ? vocab : &empty, vocab_len, bpe ? bpe : &empty, bpe_len, specials, c->host, c->err);
+    } catch (const std::bad_alloc&) {
+        return fail(c, GZ_E_NOMEM, "out of host memory while building tables");
+    } catch (...) {
+        return fail(c, GZ_E_INVALID, "unexpected failure while building tables");
+    }
+    if (rc) return rc;
+    GzHostTables& H = c->host;
+    if ((rc = upload(c, c->t_pair, H.pair_tab))) return rc;
+    if ((rc = upload(c, c->t_merges, H.merges))) return rc;
+    if ((rc = upload(c, c->t_symids, H.sym_ids))) return rc;
+    if ((rc = upload(c, c->t_bmp, H.bmp))) return rc;
+    if (!H.astral.empty()) { if ((rc = upload(c, c->t_astral, H.astral))) return rc; }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    GzDeviceTables& D = c->dev;
+    D.pair_tab = (const uint64_t*)c->t_pair.p;   D.pair_mask = (uint32_t)H.pair_tab.size() - 1;
+    D.merges = (const GzMergeInfo*)c->t_merges.p; D.n_ranks = (uint32_t)H.merges.size();
+    D.sym_ids = (const GzSymIds*)c->t_symids.p;  D.n_symbols = (uint32_t)H.symbols.size();
+    D.bmp = (const GzCpSyms*)c->t_bmp.p;
+    D.astral = H.astral.empty() ? nullptr : (const GzAstral*)c->t_astral.p;
+    D.astral_mask = H.astral.empty() ? 0 : (uint32_t)H.astral.size() - 1;
+    D.pad_id = H.special_ids[0]; D.bos_id = H.special_ids[1]; D.eos_id = H.special_ids[2]; D.unk_id = H.special_ids[4];
+    c->have_tables = true;
+    return GZ_OK;
+}
+
+int gz_table_info(gz_ctx* c, int32_t* vocab_size, int32_t special_ids[5], int32_t* n_ranks, int32_t* n_symbols)
+{
+    if (!c) return GZ_E_INVALID;
+    if (!c->have_tables) return fail(c, GZ_E_NOTABLES, "gz_load_tables has not been called");
+    if (vocab_size) *vocab_size = (int32_t)c->host.enc_words.size();
+    if (special_ids) for (int i = 0; i < 5; ++i) special_ids[i] = c->host.special_ids[i];
+    if (n_ranks) *n_ranks = (int32_t)c->host.rank_keys.size();
+    if (n_symbols) *n_symbols = (int32_t)c->host.symbols.size();
+    return GZ_OK;
+}
+
+int gz_vocab_entry(gz_ctx* c, int64_t i, const uint8_t** utf8, int32_t* len, int32_t* id)
+{
+    if (!c || !c->have_tables) return c ? fail(c, GZ_E_NOTABLES, "no tables") : GZ_E_INVALID;
+    if (i < 0 || i >= (int64_t)c->host.enc_words.size()) return GZ_E_INVALID;
+    if (utf8) *utf8 = (const uint8_t*)c->host.enc_words[i].data();
+    if (len) *len = (int32_t)c->host.enc_words[i].size();
+    if (id) *id = c->host.enc_ids[i];
+    return GZ_OK;
+}
+
+int gz_merge_entry(gz_ctx* c, int64_t i, const uint8_t** utf8, int32_t* len, int32_t* n_fields, int32_t* rank)
+{
+    if (!c || !c->have_tables) return c ? fail(c, GZ_E_NOTABLES, "no tables") : GZ_E_INVALID;
+    if (i < 0 || i >= (int64_t)c->host.rank_keys.size()) return GZ_E_INVALID;
+    if (utf8) *utf8 = (const uint8_t*)c->host.rank_keys[i].data();
+    if (len) *len = (int32_t)c->host.rank_keys[i].size();
+    if (n_fields) *n_fields = c->host.rank_nfields[i];
+    if (rank) *rank = c->host.rank_vals[i];
+    return GZ_OK;
+}
+
+int gz_symbol_utf8(gz_ctx* c, int32_t symbol, const uint8_t** utf8, int32_t* len)
+{
+    if (!c || !c->have_tables) return c ? fail(c, GZ_E_NOTABLES, "no tables") : GZ_E_INVALID;
+    if (symbol < 0 || symbol >= (int32_t)c->host.symbols.size()) return GZ_E_INVALID;
+    if (utf8) *utf8 = (const uint8_t*)c->host.symbols[symbol].data();
+    if (len) *len = (int32_t)c->host.symbols[symbol].size();
+    return GZ_OK;
+}
+
+int gz_encode_batch_device(gz_ctx* c, const uint8_t* text, const int64_t* text_off, const uint8_t* pair,
+                           const int64_t* pair_off, int64_t n_docs, int32_t max_len, uint32_t flags, int64_t capacity,
+                           int32_t* input_ids, int32_t* attention_mask, int32_t* token_type_ids, int32_t* sequence_id,
+                           int64_t* row_off, int32_t* pair_len, int32_t* n_real, int32_t* status)
+{
+    if (!c) return GZ_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    return encode_device_locked(c, text, text_off, pair, pair_off, n_docs, max_len, flags, capacity, input_ids,
+                                attention_mask, token_type_ids, sequence_id, row_off, pair_len, n_real, status, -1);
+}
+
+int gz_sync(gz_ctx* c)
+{
+    if (!c) return GZ_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    return sync_locked(c);
+}
+
+int gz_encode_batch(gz_ctx* c, const uint8_t* text, const int64_t* text_off, const uint8_t* pair,
+                    const int64_t* pair_off, int64_t n_docs, int32_t max_len, uint32_t flags, int64_t capacity,
+                    int32_t* input_ids, int32_t* attention_mask, int32_t* token_type_ids, int32_t* sequence_id,
+                    int64_t* row_off, int32_t* pair_len, int32_t* n_real, int32_t* status)
+{
+    if (!c) return GZ_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->have_tables) return fail(c, GZ_E_NOTABLES, "gz_load_tables has not been called");
+    if (n_docs < 0 || !text_off) return fail(c, GZ_E_INVALID, "bad text arguments");
+    if ((pair == nullptr) != (pair_off == nullptr) && n_docs > 0)
+        return fail(c, GZ_E_INVALID, "pair and pair_off must both be given or both be NULL");
+    if (!input_ids || !attention_mask) return fail(c, GZ_E_INVALID, "input_ids / attention_mask are required");
+    const bool is_pair = pair_off != nullptr;
+    if (is_pair && (!token_type_ids || !sequence_id || !pair_len || !status))
+        return fail(c, GZ_E_INVALID, "pair mode needs token_type_ids, sequence_id, pair_len and status");
+    for (int64_t i = 0; i < n_docs; ++i) {
+        if (text_off[i + 1] < text_off[i]) return fail(c, GZ_E_INVALID, "text_off is not non-decreasing at %lld", (long long)i);
+        if (is_pair && pair_off[i + 1] < pair_off[i]) return fail(c, GZ_E_INVALID, "pair_off is not non-decreasing at %lld", (long long)i);
+    }
+    const GzShape S = make_shape(max_len, flags);
+    const bool dense = is_dense(S);
+    if (dense && capacity < n_docs * (int64_t)max_len) return fail(c, GZ_E_CAPACITY, "capacity < n_docs*max_len");
+    if (!dense && !row_off) return fail(c, GZ_E_INVALID, "row_off is required for ragged layouts");
+    if (n_docs == 0) { if (row_off) row_off[0] = 0; return GZ_OK; }
+
+    hipStream_t s = c->stream;
+    const int64_t tb = text_off[n_docs] - text_off[0];
+    const int64_t pb = is_pair ? pair_off[n_docs] - pair_off[0] : 0;
+    int rc;
+    if ((rc = ensure(c, c->w_text, (size_t)tb + 16))) return rc;
+    if ((rc = ensure(c, c->w_toff, (size_t)(n_docs + 1) * 8))) return rc;
+    if (tb) HIPCHK(c, hipMemcpyAsync(c->w_text.p, text + text_off[0], (size_t)tb, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemcpyAsync(c->w_toff.p, text_off, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice, s));
+    const uint8_t* d_text = (const uint8_t*)c->w_text.p - text_off[0];
+    const uint8_t* d_pair = nullptr;
+    if (is_pair) {
+        if ((rc = ensure(c, c->w_pair, (size_t)pb + 16))) return rc;
+        if ((rc = ensure(c, c->w_poff, (size_t)(n_docs + 1) * 8))) return rc;
+        if (pb) HIPCHK(c, hipMemcpyAsync(c->w_pair.p, pair + pair_off[0], (size_t)pb, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(c->w_poff.p, pair_off, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice, s));
+        d_pair = (const uint8_t*)c->w_pair.p - pair_off[0];
+    }
+    // device-side outputs: dense -> n_docs*max_len; ragged -> worst case is known only after the encode kernel,
+    // so size them by the bound  rows <= max(raw tokens, max_len)  with raw tokens <= bytes + 2 (+2)
+    const int64_t raw_elems = tb + pb + (is_pair ? 4 : 2) * n_docs;
+    int64_t out_elems = dense ? n_docs * (int64_t)max_len : raw_elems;
+    if (!dense && S.pad_mode && max_len > 0) out_elems += n_docs * (int64_t)max_len;
+    if ((rc = ensure(c, c->w_ids, (size_t)out_elems * 4 + 16))) return rc;
+    if ((rc = ensure(c, c->w_mask, (size_t)out_elems * 4 + 16))) return rc;
+    if ((rc = ensure(c, c->w_nreal, (size_t)(n_docs + 1) * 4))) return rc;
+    if ((rc = ensure(c, c->w_rowoff, (size_t)(n_docs + 1) * 8))) return rc;
+    if (is_pair) {
+        if ((rc = ensure(c, c->w_tt, (size_t)out_elems * 4 + 16))) return rc;
+        if ((rc = ensure(c, c->w_seq, (size_t)out_elems * 4 + 16))) return rc;
+        if ((rc = ensure(c, c->w_pairlen, (size_t)(n_docs + 1) * 8))) return rc;
+    }
+    DBuf st2;   // status needs its own buffer in ragged mode (w_status holds the raw counts there)
+    if (is_pair) { if ((rc = ensure(c, st2, (size_t)(n_docs + 1) * 4))) return rc; }
+    rc = encode_device_locked(c, d_text, (const int64_t*)c->w_toff.p, d_pair, is_pair ? (const int64_t*)c->w_poff.p : nullptr,
+                              n_docs, max_len, flags, out_elems, (int32_t*)c->w_ids.p, (int32_t*)c->w_mask.p,
+                              is_pair ? (int32_t*)c->w_tt.p : nullptr, is_pair ? (int32_t*)c->w_seq.p : nullptr,
+                              (int64_t*)c->w_rowoff.p, is_pair ? (int32_t*)c->w_pairlen.p : nullptr,
+                              (int32_t*)c->w_nreal.p, is_pair ? (int32_t*)st2.p : nullptr, raw_elems);
+    if (rc == GZ_OK) rc = sync_locked(c);
+    if (rc) { release(st2); return rc; }
+
+    int64_t total = n_docs * (int64_t)max_len;
+    if (!dense) {
+        HIPCHK(c, hipMemcpy(row_off, c->w_rowoff.p, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost));
+        total = row_off[n_docs];
+        if (total > capacity) { release(st2); return fail(c, GZ_E_CAPACITY, "ragged output needs %lld entries, capacity is %lld", (long long)total, (long long)capacity); }
+    } else if (row_off) {
+        for (int64_t i = 0; i <= n_docs; ++i) row_off[i] = i * (int64_t)max_len;
+    }
+    if (total) {
+        HIPCHK(c, hipMemcpy(input_ids, c->w_ids.p, (size_t)total * 4, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(attention_mask, c->w_mask.p, (size_t)total * 4, hipMemcpyDeviceToHost));
+        if (is_pair) {
+            HIPCHK(c, hipMemcpy(token_type_ids, c->w_tt.p, (size_t)total * 4, hipMemcpyDeviceToHost));
+            HIPCHK(c, hipMemcpy(sequence_id, c->w_seq.p, (size_t)total * 4, hipMemcpyDeviceToHost));
+        }
+    }
+    if (is_pair) {
+        HIPCHK(c, hipMemcpy(pair_len, c->w_pairlen.p, (size_t)n_docs * 8, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(status, st2.p, (size_t)n_docs * 4, hipMemcpyDeviceToHost));
+    } else if (status) {
+        std::memset(status, 0, (size_t)n_docs * 4);
+    }
+    if (n_real) HIPCHK(c, hipMemcpy(n_real, c->w_nreal.p, (size_t)n_docs * 4, hipMemcpyDeviceToHost));
+    release(st2);
+    return GZ_OK;
+}
+
+int64_t gz_bpe_word(gz_ctx* c, const uint8_t* word, int64_t len, int32_t* pieces, int64_t cap)
+{
+    if (!c) return GZ_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->have_tables) return fail(c, GZ_E_NOTABLES, "gz_load_tables has not been called");
+    if (len <= 0 || !word || !pieces || cap <= 0 || len > 0x3FFFFFFF) return fail(c, GZ_E_INVALID, "bad arguments");
+    if (c->pend.active) { int rc = sync_locked(c); if (rc) return rc; }
+    int rc;
+    if ((rc = ensure(c, c->w_word, (size_t)len + 16))) return rc;
+    if ((rc = ensure(c, c->w_wordout, (size_t)len * 4 + 16))) return rc;
+    if ((rc = ensure(c, c->w_arena, (size_t)len * 4 + 16))) return rc;
+    hipStream_t s = c->stream;
+    HIPCHK(c, hipMemcpyAsync(c->w_word.p, word, (size_t)len, hipMemcpyHostToDevice, s));
+    gz_launch_bpe_word(c->dev, (const uint8_t*)c->w_word.p, len, (uint32_t*)c->w_arena.p, (int32_t*)c->w_wordout.p,
+                       (int32_t)len, (int32_t*)c->w_flags.p + 2, s);
+    HIPCHK(c, hipMemcpyAsync(c->h_flags + 2, (int32_t*)c->w_flags.p + 2, 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    HIPCHK(c, hipGetLastError());
+    const int64_t n = c->h_flags[2];
+    if (n > cap) return fail(c, GZ_E_CAPACITY, "word has %lld pieces, capacity %lld", (long long)n, (long long)cap);
+    HIPCHK(c, hipMemcpy(pieces, c->w_wordout.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    for (int64_t i = 0; i < n; ++i) {
+        const uint32_t v = (uint32_t)pieces[i];
+        if (v & GZ_SYM_UNKNOWN) pieces[i] = -(int32_t)(v & 0x1FFFFFu) - 1;
+    }
+    return n;
+}
+
+int gz_device_alloc(gz_ctx* c, size_t bytes, void** dptr)
+{
+    if (!c || !dptr) return GZ_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipError_t e = hipMalloc(dptr, bytes + 256);
+    if (e != hipSuccess) { *dptr = nullptr; return fail(c, GZ_E_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
+    return GZ_OK;
+}
+
+int gz_device_free(gz_ctx* c, void* dptr)
+{
+    if (!c) return GZ_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (dptr) HIPCHK(c, hipFree(dptr));
+    return GZ_OK;
+}
+
+int gz_memcpy_h2d(gz_ctx* c, void* dst, const void* src, size_t bytes)
+{
+    if (!c) return GZ_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (bytes) HIPCHK(c, hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return GZ_OK;
+}
+
+int gz_memcpy_d2h(gz_ctx* c, void* dst, const void* src, size_t bytes)
+{
+    if (!c) return GZ_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (bytes) HIPCHK(c, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return GZ_OK;
+}
+
+int gz_timing(gz_ctx* c, double out_ms[4])
+{
+    if (!c || !out_ms) return GZ_E_INVALID;
+    for (int i = 0; i < 4; ++i) out_ms[i] = c->timing[i];
+    return GZ_OK;
+}
+
+// ---- host-only table build (diagnostics, offline checks; no GPU) ------------------------------------------------------
+struct gz_host_tables { GzHostTables T; };
+
+int gz_host_tables_create(const uint8_t* vocab, size_t vocab_len, const uint8_t* bpe, size_t bpe_len,
+                          const char* const specials[5], gz_host_tables** out)
+{
+    if (!out || !specials) return GZ_E_INVALID;
+    *out = nullptr;
+    gz_host_tables* h = new (std::nothrow) gz_host_tables();
+    if (!h) return GZ_E_NOMEM;
+    static const uint8_t empty = 0;
+    int rc;
+    try {
+        std::string err;
+        rc = gz_build_tables(vocab ? vocab : &empty, vocab_len, bpe ? bpe : &empty, bpe_len, specials, h->T, err);
+        if (rc) g_create_err = err;
+    } catch (...) {
+        rc = GZ_E_NOMEM;
+    }
+    if (rc) { delete h; return rc; }
+    *out = h;
+    return GZ_OK;
+}
+
+void gz_host_tables_destroy(gz_host_tables* t) { delete t; }
+
+int gz_host_tables_array(gz_host_tables* t, int which, const void** data, int64_t* count)
+{
+    if (!t || !data || !count) return GZ_E_INVALID;
+    GzHostTables& H = t->T;
+    switch (which) {
+        case 0: *data = H.pair_tab.data(); *count = (int64_t)H.pair_tab.size(); break;
+        case 1: *data = H.merges.data();   *count = (int64_t)H.merges.size(); break;
+        case 2: *data = H.sym_ids.data();  *count = (int64_t)H.sym_ids.size(); break;
+        case 3: *data = H.bmp.data();      *count = (int64_t)H.bmp.size(); break;
+        case 4: *data = H.astral.data();   *count = (int64_t)H.astral.size(); break;
+        case 5: *data = H.special_ids;     *count = 5; break;
+        default: return GZ_E_INVALID;
+    }
+    return GZ_OK;
+}
+
+int gz_host_tables_vocab_entry(gz_host_tables* t, int64_t i, const uint8_t** utf8, int32_t* len, int32_t* id)
+{
+    if (!t || i < 0 || i >= (int64_t)t->T.enc_words.size()) return GZ_E_INVALID;
+    if (utf8) *utf8 = (const uint8_t*)t->T.enc_words[i].data();
+    if (len) *len = (int32_t)t->T.enc_words[i].size();
+    if (id) *id = t->T.enc_ids[i];
+    return GZ_OK;
+}
+
+int gz_host_tables_merge_entry(gz_host_tables* t, int64_t i, const uint8_t** utf8, int32_t* len, int32_t* n_fields, int32_t* rank)
+{
+    if (!t || i < 0 || i >= (int64_t)t->T.rank_keys.size()) return GZ_E_INVALID;
+    if (utf8) *utf8 = (const uint8_t*)t->T.rank_keys[i].data();
+    if (len) *len = (int32_t)t->T.rank_keys[i].size();
+    if (n_fields) *n_fields = t->T.rank_nfields[i];
+    if (rank) *rank = t->T.rank_vals[i];
+    return GZ_OK;
+}
+
+int gz_host_tables_symbol(gz_host_tables* t, int32_t symbol, const uint8_t** utf8, int32_t* len)
+{
+    if (!t || symbol < 0 || symbol >= (int32_t)t->T.symbols.size()) return GZ_E_INVALID;
+    if (utf8) *utf8 = (const uint8_t*)t->T.symbols[symbol].data();
+    if (len) *len = (int32_t)t->T.symbols[symbol].size();
+    return GZ_OK;
+}
+
+// ---- multi-GPU exchange step --------------------------------------------------------------------------------------
+int gz_comm_unique_id(uint8_t id_out[128])
+{
+    if (!id_out) return GZ_E_INVALID;
+    if (!rccl_load()) return fail(nullptr, GZ_E_RCCL, "librccl.so could not be loaded");
+    int r = g_rccl.GetUniqueId(id_out);
+    return r == 0 ? GZ_OK : fail(nullptr, GZ_E_RCCL, "ncclGetUniqueId failed (%d)", r);
+}
+
+int gz_comm_init(gz_ctx* c, const uint8_t id[128], int rank, int world)
+{
+    if (!c || !id || world < 1 || rank < 0 || rank >= world) return c ? fail(c, GZ_E_INVALID, "bad arguments") : GZ_E_INVALID;
+    if (!rccl_load()) return fail(c, GZ_E_RCCL, "librccl.so could not be loaded");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->comm) { g_rccl.CommDestroy(c->comm); c->comm = nullptr; }
+    Id128 uid;
+    std::memcpy(uid.b, id, 128);
+    int r = g_rccl.CommInitRank(&c->comm, world, uid, rank);
+    if (r != 0) { c->comm = nullptr; return fail(c, GZ_E_RCCL, "ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error"); }
+    c->rank = rank; c->world = world;
+    return GZ_OK;
+}
+
+int gz_gather_rows(gz_ctx* c, const int32_t* send_dev, int64_t n_rows_local, int32_t row_len, int32_t* recv_dev,
+                   const int64_t* rows_per_rank, int root)
+{
+    if (!c) return GZ_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->comm) return fail(c, GZ_E_RCCL, "gz_comm_init has not been called");
+    if (root < 0 || root >= c->world || row_len <= 0 || n_rows_local < 0 || !rows_per_rank)
+        return fail(c, GZ_E_INVALID, "bad arguments");
+    HIPCHK(c, hipSetDevice(c->device));
+    const int ncclInt32 = 2;
+    // direct gatherv: the root posts one receive per peer, each peer one send, all inside one group, so every
+    // peer's block travels over its own xGMI link concurrently (no ring)
+    int r = g_rccl.GroupStart();
+    if (r == 0 && c->rank == root) {
+        int64_t row0 = 0;
+        for (int q = 0; q < c->world && r == 0; ++q) {
+            const size_t cnt = (size_t)rows_per_rank[q] * (size_t)row_len;
+            int32_t* dst = recv_dev + row0 * (int64_t)row_len;
+            if (q == root) {
+                if (cnt && dst != send_dev)
+                    HIPCHK(c, hipMemcpyAsync(dst, send_dev, cnt * 4, hipMemcpyDeviceToDevice, c->stream));
+            } else if (cnt) {
+                r = g_rccl.Recv(dst, cnt, ncclInt32, q, c->comm, c->stream);
+            }
+            row0 += rows_per_rank[q];
+        }
+    } else if (r == 0) {
+        const size_t cnt = (size_t)n_rows_local * (size_t)row_len;
+        if (cnt) r = g_rccl.Send(send_dev, cnt, ncclInt32, root, c->comm, c->stream);
+    }
+    int r2 = g_rccl.GroupEnd();
+    if (r != 0 || r2 != 0)
+        return fail(c, GZ_E_RCCL, "RCCL gather failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r ? r : r2) : "error");
+    return GZ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,84 @@
+// Shared between the host table builder (gz_tables.cpp), the kernels (gz_kernels.hip) and the C ABI (gz_api.cpp).
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define GZ_HD __host__ __device__ __forceinline__
+#else
+#define GZ_HD inline
+#endif
+
+// ---------------------------------------------------------------------------------------------------------
+// Symbol values as the kernels hold them
+//   bit 31 clear : interned symbol id (< GZ_MAX_SYMBOLS).  A symbol is a STRING of the reference's bpe()
+//                  (tokenize.py:62-101): two merge histories that spell the same string are one symbol.
+//   bit 31 set   : a code point that is in no merge and no vocab entry (low 21 bits = code point,
+//                  bit 30 = it is the word's last character).  It can never merge and maps to the unk id.
+// ---------------------------------------------------------------------------------------------------------
+constexpr uint32_t GZ_MAX_SYMBOLS = (1u << 20) - 2;   // ids 0 .. 2^20-3; 0xFFFFF is reserved (empty key)
+constexpr uint32_t GZ_MAX_RANKS   = (1u << 24) - 1;   // merge-file line numbers
+constexpr uint32_t GZ_SYM_UNKNOWN = 0x80000000u;
+constexpr uint32_t GZ_SYM_LASTBIT = 0x40000000u;
+constexpr uint32_t GZ_NO_SYMBOL   = 0xFFFFFFFFu;      // table entry: code point has no interned symbol
+constexpr uint32_t GZ_RANK_NONE   = 0xFFFFFFFFu;      // "pair is not in bpe_ranks" (the float('inf') of tokenize.py:71)
+constexpr uint64_t GZ_PAIR_EMPTY  = ~0ull;
+
+// pair -> rank hash table entry:  [ left:20 | right:20 | rank:24 ]
+GZ_HD uint64_t gz_pair_key(uint32_t a, uint32_t b) { return ((uint64_t)a << 20) | b; }
+GZ_HD uint64_t gz_pair_entry(uint32_t a, uint32_t b, uint32_t rank) { return (gz_pair_key(a, b) << 24) | rank; }
+GZ_HD uint32_t gz_pair_hash(uint32_t a, uint32_t b)
+{
+    uint32_t h = a * 0x9E3779B1u + b * 0x85EBCA6Bu;
+    h ^= h >> 15;
+    h *= 0x2C1B3C6Du;
+    h ^= h >> 13;
+    return h;
+}
+GZ_HD uint32_t gz_cp_hash(uint32_t cp)
+{
+    uint32_t h = cp * 0x9E3779B1u;
+    return h ^ (h >> 16);
+}
+
+struct GzMergeInfo { uint32_t left, right, merged, pad; };   // indexed by rank
+struct GzSymIds    { int32_t nonfinal, final_; };            // vocab id of  sym+"@@"  /  sym minus "</w>"
+struct GzCpSyms    { uint32_t plain, final_; };              // symbol of  c  /  c+"</w>"   (GZ_NO_SYMBOL if none)
+struct GzAstral    { uint32_t cp, plain, final_, pad; };     // open-addressing entry, cp == GZ_NO_SYMBOL -> empty
+
+// Device-resident tables, passed to kernels by value.
+struct GzDeviceTables {
+    const uint64_t*    pair_tab;    uint32_t pair_mask;      // slots-1 (power of two)
+    const GzMergeInfo* merges;      uint32_t n_ranks;
+    const GzSymIds*    sym_ids;     uint32_t n_symbols;
+    const GzCpSyms*    bmp;                                   // 65536 entries
+    const GzAstral*    astral;      uint32_t astral_mask;    // slots-1; astral == nullptr when no astral symbol exists
+    int32_t pad_id, bos_id, eos_id, unk_id;
+};
+
+// Host-side result of the loader (tokenize.py:31-57) and of the table build.
+struct GzHostTables {
+    // encoder in insertion order (Python dict order): word bytes, id (ids can repeat: rule L3)
+    std::vector<std::string> enc_words;
+    std::vector<int32_t>     enc_ids;
+    int32_t special_ids[5] = {0, 0, 0, 0, 0};
+    // bpe_ranks in insertion order: fields joined by '\n', field count, rank
+    std::vector<std::string> rank_keys;
+    std::vector<int32_t>     rank_nfields;
+    std::vector<int32_t>     rank_vals;
+    // interned symbols
+    std::vector<std::string> symbols;
+    // device images
+    std::vector<uint64_t>    pair_tab;
+    std::vector<GzMergeInfo> merges;
+    std::vector<GzSymIds>    sym_ids;
+    std::vector<GzCpSyms>    bmp;
+    std::vector<GzAstral>    astral;     // empty when unused
+    uint32_t max_probe = 0;
+};
+
+// Returns GZ_OK / GZ_E_UTF8 / GZ_E_LIMIT; `err` receives a message.
+int gz_build_tables(const uint8_t* vocab, size_t vocab_len, const uint8_t* bpe, size_t bpe_len,
+                    const char* const specials[5], GzHostTables& out, std::string& err);

@@ -1,0 +1,56 @@
+// Kernel argument blocks and launchers (gz_kernels.hip) used by the C ABI (gz_api.cpp).
+#pragma once
+#include "gz_common.h"
+#include <hip/hip_runtime.h>
+
+constexpr int GZ_WAVES_PER_BLOCK = 4;
+constexpr int32_t GZ_DEFERRED = -1;     // n_real value of a document waiting for the arena pass
+constexpr int32_t GZ_NONE_ = -1;        // == GZ_NONE of the public header
+
+// max_len / padding / truncation of Tokenize.__call__ (tokenize.py:184-190)
+struct GzShape {
+    int32_t max_len;      // meaningful only when pad_mode
+    int32_t pad_mode;     // `max_len is not None and padding` (tokenize.py:247, :256)
+    int32_t truncation;
+};
+
+struct GzEncodeArgs {
+    const uint8_t* text;  const int64_t* text_off;
+    const uint8_t* pair;  const int64_t* pair_off;    // nullptr -> single-text mode
+    int64_t n_docs;
+    int32_t dense;        // rows of exactly max_len entries, written in place
+    int32_t max_len;
+    int32_t* ids;         // dense: [n_docs, max_len]
+    int32_t* mask;        // dense: [n_docs, max_len]
+    int32_t* raw;         // ragged: raw framed ids, document d at (text bytes before d) + (pair bytes before d) + 2d (+2d)
+    int32_t* n_real;      // [n_docs] dense: min(T, max_len); ragged: T (raw token count); GZ_DEFERRED
+    int32_t* defer_flag;  // set to 1 when some document needs the arena
+    uint32_t* arena;      // nullptr, or 4 bytes per input byte (text then pair)
+    int32_t huge_pass;    // 1: only documents whose n_real == GZ_DEFERRED
+};
+
+struct GzFinalizeArgs {
+    const int64_t* text_off; const int64_t* pair_off;
+    int64_t n_docs;
+    GzShape S;
+    const int32_t* raw; const int32_t* n_raw;
+    int64_t* row_off;     // [n_docs+1] (written by the scan that precedes the finalize kernel)
+    int64_t capacity;
+    int32_t* ids; int32_t* mask; int32_t* n_real;
+    int32_t* error_flag;  // set to 1 when row_off[n_docs] > capacity
+};
+
+struct GzPairArgs {
+    int64_t n_docs;
+    GzShape S;            // dense when row_off == nullptr (rows of max_len)
+    const int64_t* row_off; int64_t capacity;
+    const int32_t* ids;
+    int32_t* seq; int32_t* tt; int32_t* pair_len; int32_t* status;
+};
+
+void gz_launch_encode(const GzDeviceTables& T, const GzEncodeArgs& A, hipStream_t s);
+void gz_launch_rowscan(const GzFinalizeArgs& F, int64_t* row_len_tmp, hipStream_t s);
+void gz_launch_finalize(const GzDeviceTables& T, const GzFinalizeArgs& F, hipStream_t s);
+void gz_launch_pair(const GzDeviceTables& T, const GzPairArgs& P, hipStream_t s);
+void gz_launch_bpe_word(const GzDeviceTables& T, const uint8_t* word, int64_t nbytes, uint32_t* arena,
+                        int32_t* out, int32_t cap, int32_t* n_out, hipStream_t s);

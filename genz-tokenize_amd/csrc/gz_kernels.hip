@@ -1,0 +1,729 @@
+// HIP kernels of the genz-tokenize hot path for gfx950 (MI355X, wave64).
+//
+//   gz_encode_kernel     K1+K2+K3 fused: one wavefront per document.  Coalesced 16-B loads stage 1-KiB tiles of
+//                        the packed UTF-8 through LDS; per-lane SWAR-free classification + wave prefix sums give
+//                        the word list (Unicode whitespace split with the "\S+\n?" glue rule, tokenize.py:106);
+//                        one lane per word runs the BPE merge loop (tokenize.py:62-101) against the pair->rank
+//                        hash in HBM/L2 with its symbols in LDS; ids come from the symbol->vocab-id table
+//                        (tokenize.py:120-121) and are framed, truncated, padded and masked in place
+//                        (tokenize.py:126-152, :184-251).  Words longer than 16 symbols run wave-cooperatively
+//                        (ballot + prefix-sum compaction), in LDS up to 1024 symbols, in a global arena beyond.
+//   gz_rowlen_kernel / gz_scan_kernel / gz_finalize_kernel   ragged layouts only (padding=False, truncation=False,
+//                        max_len None or < 1): row lengths, exclusive scan, copy + pad/cut (tokenize.py:141-146).
+//   gz_pair_kernel       sequence_id / token_type_ids of sentence pairs (tokenize.py:154-182, :252-258).
+//   gz_bpe_word_kernel   Tokenize.bpe(token) for one word (symbols out).
+//
+// Integer / byte work only: no MFMA.  Everything is bit-exact with the reference by construction; see DESIGN.md.
+#include "gz_kernels.h"
+
+namespace {
+
+constexpr int WAVE = 64;
+constexpr int WPB = GZ_WAVES_PER_BLOCK;      // waves (documents) per workgroup
+constexpr int TILE = 1024;                   // bytes classified per tile: 16 per lane
+constexpr int MAXSYM = 16;                   // symbols a lane-per-word merge holds
+constexpr int LONGCAP = WAVE * MAXSYM;       // symbols the wave-cooperative LDS path holds (same LDS region)
+constexpr int MAXWORDS = TILE / 2 + 1;       // a word needs >= 1 byte + >= 1 whitespace byte
+
+struct WaveLds {
+    uint32_t bytes[(TILE + 16) / 4];         // tile bytes + 16 look-ahead bytes
+    uint32_t sym[LONGCAP];                   // lane-per-word: sym[k*64 + lane]; long path: sym[i]
+    uint16_t wstart[MAXWORDS + 3];
+    uint16_t wend[MAXWORDS + 3];
+};
+
+__device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
+__device__ __forceinline__ uint64_t lt_mask(int lane) { return (1ull << lane) - 1ull; }
+
+__device__ __forceinline__ int wave_excl_sum(int v, int lane, int& total)
+{
+    int x = v;
+#pragma unroll
+    for (int d = 1; d < WAVE; d <<= 1) {
+        int y = __shfl_up(x, d, WAVE);
+        if (lane >= d) x += y;
+    }
+    total = __shfl(x, WAVE - 1, WAVE);
+    return x - v;
+}
+
+__device__ __forceinline__ uint32_t wave_min_u32(uint32_t v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        uint32_t y = (uint32_t)__shfl_xor((int)v, d, WAVE);
+        v = y < v ? y : v;
+    }
+    return v;
+}
+
+__device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, WAVE);
+    return v;
+}
+
+// bpe_ranks.get(pair, inf)  (tokenize.py:70-71)
+__device__ __forceinline__ uint32_t probe_rank(const GzDeviceTables& T, uint32_t a, uint32_t b)
+{
+    if ((a | b) & 0xFFF00000u) return GZ_RANK_NONE;          // a code point outside every table never merges
+    uint32_t h = gz_pair_hash(a, b) & T.pair_mask;
+    const uint64_t key = gz_pair_key(a, b);
+    for (;;) {
+        uint64_t e = T.pair_tab[h];
+        if ((e >> 24) == key) return (uint32_t)e & 0xFFFFFFu;
+        if (e == GZ_PAIR_EMPTY) return GZ_RANK_NONE;
+        h = (h + 1) & T.pair_mask;
+    }
+}
+
+// tuple(token) / word[-1] + "</w>"  (tokenize.py:63-64): code point -> initial symbol
+__device__ __forceinline__ uint32_t initial_symbol(const GzDeviceTables& T, uint32_t cp, bool last)
+{
+    uint32_t s = GZ_NO_SYMBOL;
+    if (cp < 0x10000u) {
+        GzCpSyms e = T.bmp[cp];
+        s = last ? e.final_ : e.plain;
+    } else if (T.astral != nullptr) {
+        uint32_t h = gz_cp_hash(cp) & T.astral_mask;
+        for (;;) {
+            GzAstral e = T.astral[h];
+            if (e.cp == cp) { s = last ? e.final_ : e.plain; break; }
+            if (e.cp == GZ_NO_SYMBOL) break;
+            h = (h + 1) & T.astral_mask;
+        }
+    }
+    return s == GZ_NO_SYMBOL ? (GZ_SYM_UNKNOWN | cp) : s;
+}
+
+// encoder.get(piece, encoder.get(unk))  (tokenize.py:120-121)
+__device__ __forceinline__ int32_t token_id(const GzDeviceTables& T, uint32_t s, bool final_piece)
+{
+    if (s & GZ_SYM_UNKNOWN) return T.unk_id;
+    GzSymIds e = T.sym_ids[s];
+    return final_piece ? e.final_ : e.nonfinal;
+}
+
+// Structural UTF-8 decode of the code point whose lead byte is at index i; never reads at or past `end`.
+template <class ByteAt>
+__device__ __forceinline__ uint32_t decode_cp(ByteAt&& at, int64_t i, int64_t end, int& len)
+{
+    uint32_t b0 = at(i);
+    int want = b0 < 0x80 ? 1 : b0 < 0xE0 ? 2 : b0 < 0xF0 ? 3 : 4;
+    if (i + want > end) want = (int)(end - i);
+    len = want;
+    if (b0 < 0x80) return b0;
+    uint32_t cp = want == 2 ? (b0 & 0x1F) : want == 3 ? (b0 & 0x0F) : want == 4 ? (b0 & 0x07) : (b0 & 0x3F);
+    for (int k = 1; k < want; ++k) cp = (cp << 6) | (at(i + k) & 0x3F);
+    return cp;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Per-wave encoder state
+// ---------------------------------------------------------------------------------------------------------------
+struct Emit {
+    int32_t* ids;        // destination row (dense: final input_ids row; ragged: raw row in the workspace)
+    int32_t* mask;       // dense only
+    int32_t* symout;     // gz_bpe_word: raw symbols instead of ids
+    int limit;           // positions >= limit are dropped (dense: max_len-1)
+    int stop;            // stop tokenizing once ntok >= stop (dense: max_len)
+    int ntok;            // wave-uniform count of raw tokens so far
+    int32_t pad_id;
+};
+
+__device__ __forceinline__ void emit_at(const Emit& E, int pos, int32_t id)
+{
+    if (pos < E.limit) {
+        E.ids[pos] = id;
+        if (E.mask) E.mask[pos] = id != E.pad_id ? 1 : 0;
+    }
+}
+
+__device__ __forceinline__ void emit_uniform(Emit& E, int32_t id, int lane)
+{
+    if (lane == 0) emit_at(E, E.ntok, id);
+    E.ntok += 1;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Wave-cooperative merge loop over S[0..n) (LDS or global scratch).  tokenize.py:69-98.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ int wave_merge(const GzDeviceTables& T, uint32_t* S, int n, int lane, bool global_scratch)
+{
+    while (n > 1) {
+        uint32_t best = GZ_RANK_NONE;
+        for (int i = lane; i < n - 1; i += WAVE) {
+            uint32_t r = probe_rank(T, S[i], S[i + 1]);
+            best = r < best ? r : best;
+        }
+        best = wave_min_u32(best);                         // min(pairs, key=rank)
+        if (best == GZ_RANK_NONE) break;                   // "bigram not in self.bpe_ranks"
+        const GzMergeInfo mi = T.merges[best];
+        int out = 0;
+        bool skip0 = false;                                // S[base] is the `second` of a pair merged in the previous chunk
+        for (int base = 0; base < n; base += WAVE) {
+            const int i = base + lane;
+            const uint32_t s = i < n ? S[i] : GZ_NO_SYMBOL;
+            const uint32_t s1 = i + 1 < n ? S[i + 1] : GZ_NO_SYMBOL;
+            const uint64_t valid = __ballot(i < n);
+            uint64_t m = __ballot(i + 1 < n && s == mi.left && s1 == mi.right);
+            if (skip0) m &= ~1ull;
+            uint64_t pick = m;
+            if (mi.left == mi.right) {                     // overlapping candidates: greedy left to right
+                pick = 0;
+                uint64_t rem = m;
+                while (rem) {
+                    uint64_t low = rem & (0 - rem);
+                    pick |= low;
+                    rem &= ~(low | (low << 1));
+                }
+            }
+            const uint64_t keep = valid & ~((pick << 1) | (skip0 ? 1ull : 0ull));
+            skip0 = (pick >> 63) & 1ull;
+            const uint32_t val = ((pick >> lane) & 1ull) ? mi.merged : s;
+            const int dest = out + __popcll(keep & lt_mask(lane));
+            if ((keep >> lane) & 1ull) S[dest] = val;
+            out += __popcll(keep);
+        }
+        n = out;
+        if (global_scratch) __threadfence();
+    }
+    return n;
+}
+
+// One word too long for a lane (or for a tile): bytes g[0..nbytes) in global memory, optional glued '\n'.
+// Returns false when the word needs the global arena and none was given (document is deferred).
+__device__ bool long_word(const GzDeviceTables& T, WaveLds& L, const uint8_t* g, int64_t nbytes, bool glue,
+                          uint32_t* arena_slot, Emit& E, int lane)
+{
+    auto at = [&](int64_t i) -> uint32_t { return g[i]; };
+    int leads = 0;
+    for (int64_t i = lane; i < nbytes; i += WAVE) leads += (g[i] & 0xC0) != 0x80;
+    const int64_t nsym64 = (int64_t)wave_sum(leads) + (glue ? 1 : 0);
+    uint32_t* S;
+    bool global_scratch = false;
+    if (nsym64 <= LONGCAP) S = L.sym;
+    else if (arena_slot != nullptr) { S = arena_slot; global_scratch = true; }
+    else return false;
+    int n = (int)nsym64;
+    int symbase = 0;
+    for (int64_t base = 0; base < nbytes; base += WAVE) {
+        const int64_t i = base + lane;
+        const bool lead = i < nbytes && (g[i] & 0xC0) != 0x80;
+        const uint64_t m = __ballot(lead);
+        if (lead) {
+            int len;
+            const uint32_t cp = decode_cp(at, i, nbytes, len);
+            const int idx = symbase + __popcll(m & lt_mask(lane));
+            S[idx] = initial_symbol(T, cp, !glue && idx == n - 1);
+        }
+        symbase += __popcll(m);
+    }
+    if (glue && lane == 0) S[n - 1] = initial_symbol(T, 0x0Au, true);
+    if (global_scratch) __threadfence();
+    if (n > 1) n = wave_merge(T, S, n, lane, global_scratch);
+    for (int base = 0; base < n; base += WAVE) {
+        const int i = base + lane;
+        if (i < n) {
+            if (E.symout) { if (E.ntok + i < E.limit) E.symout[E.ntok + i] = (int32_t)S[i]; }
+            else emit_at(E, E.ntok + i, token_id(T, S[i], i == n - 1));
+        }
+    }
+    E.ntok += n;
+    return true;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Tile classification: lane owns bytes [16*lane, 16*lane+16) of the tile (w[0..3]) and sees 4 more (w4).
+//   start bit j : a word starts at byte 16*lane+j   (non-whitespace lead byte whose previous byte is whitespace)
+//   end   bit j : a word ends before byte 16*lane+j (whitespace lead byte whose previous byte is not whitespace)
+// `prev_ws0`: the byte before the tile counts as whitespace (tile begins at a word boundary); then leading
+// continuation bytes (tail of a whitespace code point cut by the previous tile) count as whitespace too.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void classify(const uint32_t w[4], uint32_t w4, int lane, bool prev_ws0,
+                                         uint32_t& start16, uint32_t& end16)
+{
+    uint32_t lead = 0, ws = 0, ws23 = 0, ws3 = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        auto byte = [&](int k) -> uint32_t { return k < 16 ? (w[k >> 2] >> ((k & 3) * 8)) & 0xFFu : (w4 >> ((k - 16) * 8)) & 0xFFu; };
+        const uint32_t b = byte(j), n1 = byte(j + 1), n2 = byte(j + 2);
+        const bool is_lead = (b & 0xC0u) != 0x80u;
+        const bool a1 = b == 0x20u || (b >= 0x09u && b <= 0x0Du) || (b >= 0x1Cu && b <= 0x1Fu);
+        const bool a2 = b == 0xC2u && (n1 == 0x85u || n1 == 0xA0u);
+        const bool a3 = (b == 0xE2u && ((n1 == 0x80u && ((n2 >= 0x80u && n2 <= 0x8Au) || n2 == 0xA8u || n2 == 0xA9u || n2 == 0xAFu)) ||
+                                        (n1 == 0x81u && n2 == 0x9Fu))) ||
+                        (b == 0xE1u && n1 == 0x9Au && n2 == 0x80u) || (b == 0xE3u && n1 == 0x80u && n2 == 0x80u);
+        lead |= (uint32_t)is_lead << j;
+        ws |= (uint32_t)(a1 || a2 || a3) << j;
+        ws23 |= (uint32_t)(a2 || a3) << j;
+        ws3 |= (uint32_t)a3 << j;
+    }
+    uint32_t full = ws | (ws23 << 1) | (ws3 << 2);           // every byte of a whitespace code point (18 bits)
+    uint32_t carry = (uint32_t)__shfl_up((int)(full >> 16), 1, WAVE);
+    uint32_t prevbit = (uint32_t)__shfl_up((int)((full >> 15) & 1u), 1, WAVE);
+    if (lane == 0) {
+        carry = 0;
+        prevbit = prev_ws0 ? 1u : 0u;
+        if (prev_ws0) {
+            const uint32_t c0 = ~lead & 1u, c1 = c0 & (~lead >> 1) & 1u, c2 = c1 & (~lead >> 2) & 1u;
+            carry = c0 | (c1 << 1) | (c2 << 2);
+        }
+    }
+    full = (full | carry) & 0xFFFFu;
+    const uint32_t prev_ws = ((full << 1) | prevbit) & 0xFFFFu;
+    start16 = lead & ~ws & prev_ws & 0xFFFFu;
+    end16 = ws & ~prev_ws & 0xFFFFu;
+}
+
+// Load the tile [pos, pos+TILE+16) of a document that ends at `end` into registers (bytes past the end read as
+// spaces, which terminates the last word and can never be a glued '\n') and into LDS.
+__device__ __forceinline__ void load_tile(const uint8_t* base, int64_t pos, int64_t end, int64_t buf_end, int lane,
+                                          uint32_t w[4], uint32_t& w4, WaveLds& L)
+{
+    typedef uint4 __attribute__((aligned(1))) uint4_u;
+    const int64_t g = pos + 16 * lane;
+    int64_t nv = end - g;
+    nv = nv < 0 ? 0 : nv > 16 ? 16 : nv;
+    uint32_t r[4] = {0x20202020u, 0x20202020u, 0x20202020u, 0x20202020u};
+    if (nv > 0) {
+        if (g + 16 <= buf_end) {
+            const uint4 v = *reinterpret_cast<const uint4_u*>(base + g);
+            r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
+        } else {
+            for (int k = 0; k < (int)nv; ++k) {
+                const uint32_t sh = (k & 3) * 8;
+                r[k >> 2] = (r[k >> 2] & ~(0xFFu << sh)) | ((uint32_t)base[g + k] << sh);
+            }
+        }
+        if (nv < 16) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                int v = (int)nv - 4 * q;
+                v = v < 0 ? 0 : v > 4 ? 4 : v;
+                const uint32_t keep = v == 4 ? 0xFFFFFFFFu : ((1u << (8 * v)) - 1u);
+                r[q] = (r[q] & keep) | (0x20202020u & ~keep);
+            }
+        }
+    }
+    w[0] = r[0]; w[1] = r[1]; w[2] = r[2]; w[3] = r[3];
+    uint32_t nxt = (uint32_t)__shfl_down((int)r[0], 1, WAVE);
+    if (lane == WAVE - 1) {
+        nxt = 0x20202020u;
+        const int64_t g2 = pos + TILE;
+        for (int k = 0; k < 4; ++k)
+            if (g2 + k < end) nxt = (nxt & ~(0xFFu << (8 * k))) | ((uint32_t)base[g2 + k] << (8 * k));
+    }
+    w4 = nxt;
+    uint4* dst = reinterpret_cast<uint4*>(L.bytes);
+    dst[lane] = make_uint4(r[0], r[1], r[2], r[3]);
+    if (lane == WAVE - 1) L.bytes[TILE / 4] = nxt;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// One text (text A or text B of a document): __tokenize + ids (tokenize.py:103-133).
+// Returns false if the document must be deferred to the arena pass.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ bool encode_text(const GzDeviceTables& T, WaveLds& L, const uint8_t* base, int64_t b0, int64_t b1,
+                            int64_t buf_end, uint32_t* arena, Emit& E, int lane)
+{
+    const uint8_t* lds_bytes = reinterpret_cast<const uint8_t*>(L.bytes);
+    int64_t pos = b0;
+    while (pos < b1 && E.ntok < E.stop) {
+        uint32_t w[4], w4;
+        load_tile(base, pos, b1, buf_end, lane, w, w4, L);
+        uint32_t st16, en16;
+        classify(w, w4, lane, true, st16, en16);
+        int n_starts, n_ends;
+        int sidx = wave_excl_sum(__popc(st16), lane, n_starts);
+        int eidx = wave_excl_sum(__popc(en16), lane, n_ends);
+        for (uint32_t m = st16; m; m &= m - 1) L.wstart[sidx++] = (uint16_t)(16 * lane + __ffs(m) - 1);
+        for (uint32_t m = en16; m; m &= m - 1) L.wend[eidx++] = (uint16_t)(16 * lane + __ffs(m) - 1);
+        // (LDS traffic of one wave is ordered; no barrier is needed between its own writes and reads)
+
+        const int nw = n_ends;                                  // complete words of this tile
+        for (int wbase = 0; wbase < nw && E.ntok < E.stop; wbase += WAVE) {
+            const int wi = wbase + lane;
+            const bool have = wi < nw;
+            const int ws = have ? L.wstart[wi] : 0;
+            const int we = have ? L.wend[wi] : 0;
+            const bool glue = have && lds_bytes[we] == 0x0Au;   // "\S+\n?"
+            int seg_lo = 0;
+            for (;;) {
+                const bool act = have && lane >= seg_lo;
+                int n = 0;
+                bool is_long = false;
+                if (act) {
+                    auto at = [&](int64_t i) -> uint32_t { return lds_bytes[i]; };
+                    int i = ws;
+                    while (i < we) {
+                        int len;
+                        const uint32_t cp = decode_cp(at, i, we, len);
+                        if (n == MAXSYM) { is_long = true; break; }
+                        L.sym[n * WAVE + lane] = initial_symbol(T, cp, !glue && i + len >= we);
+                        ++n;
+                        i += len;
+                    }
+                    if (glue && !is_long) {
+                        if (n == MAXSYM) is_long = true;
+                        else { L.sym[n * WAVE + lane] = initial_symbol(T, 0x0Au, true); ++n; }
+                    }
+                }
+                const uint64_t lm = __ballot(act && is_long);
+                const int f = lm ? __ffsll((unsigned long long)lm) - 1 : WAVE;
+                const bool run = act && lane < f;
+                if (run) {
+                    // the merge loop, one lane per word (tokenize.py:69-98)
+                    while (n > 1) {
+                        uint32_t best = GZ_RANK_NONE;
+                        uint32_t a = L.sym[lane];
+                        for (int k = 1; k < n; ++k) {
+                            const uint32_t b = L.sym[k * WAVE + lane];
+                            const uint32_t r = probe_rank(T, a, b);
+                            best = r < best ? r : best;
+                            a = b;
+                        }
+                        if (best == GZ_RANK_NONE) break;
+                        const GzMergeInfo mi = T.merges[best];
+                        int j = 0, k = 0;
+                        while (k < n) {
+                            const uint32_t s = L.sym[k * WAVE + lane];
+                            if (k + 1 < n && s == mi.left && L.sym[(k + 1) * WAVE + lane] == mi.right) {
+                                L.sym[j * WAVE + lane] = mi.merged;
+                                k += 2;
+                            } else {
+                                L.sym[j * WAVE + lane] = s;
+                                k += 1;
+                            }
+                            ++j;
+                        }
+                        n = j;
+                    }
+                }
+                int total;
+                const int off = wave_excl_sum(run ? n : 0, lane, total);
+                if (run) {
+                    for (int k = 0; k < n; ++k) {
+                        const uint32_t s = L.sym[k * WAVE + lane];
+                        if (E.symout) { if (E.ntok + off + k < E.limit) E.symout[E.ntok + off + k] = (int32_t)s; }
+                        else emit_at(E, E.ntok + off + k, token_id(T, s, k == n - 1));
+                    }
+                }
+                E.ntok += total;
+                if (f == WAVE || E.ntok >= E.stop) break;
+                // word of lane f is too long for one lane
+                const int fs = __shfl(ws, f, WAVE), fe = __shfl(we, f, WAVE);
+                const bool fg = __shfl((int)glue, f, WAVE) != 0;
+                const int64_t gpos = pos + fs;
+                if (!long_word(T, L, base + gpos, fe - fs, fg, arena ? arena + gpos : nullptr, E, lane)) return false;
+                seg_lo = f + 1;
+            }
+        }
+        if (E.ntok >= E.stop) break;
+
+        if (n_starts > n_ends) {
+            const int s_last = L.wstart[n_ends];
+            if (s_last > 0) { pos += s_last; continue; }        // re-tile at the start of the cut word
+            // a word that fills the whole tile: find its end by scanning forward
+            int64_t q = pos + TILE;
+            int64_t wend_abs = b1;
+            while (q < b1) {
+                uint32_t ww[4], ww4, s2, e2;
+                load_tile(base, q, b1, buf_end, lane, ww, ww4, L);
+                classify(ww, ww4, lane, false, s2, e2);
+                const uint64_t any = __ballot(e2 != 0);
+                if (any) {
+                    const int fl = __ffsll((unsigned long long)any) - 1;
+                    const uint32_t eb = (uint32_t)__shfl((int)e2, fl, WAVE);
+                    wend_abs = q + 16 * fl + __ffs(eb) - 1;
+                    break;
+                }
+                q += TILE;
+            }
+            if (wend_abs > b1) wend_abs = b1;
+            const bool fg = wend_abs < b1 && base[wend_abs] == 0x0A;
+            if (!long_word(T, L, base + pos, wend_abs - pos, fg, arena ? arena + pos : nullptr, E, lane)) return false;
+            pos = wend_abs + (fg ? 1 : 0);
+        } else {
+            pos += TILE;
+        }
+    }
+    return true;
+}
+
+}  // namespace
+
+// =================================================================================================================
+// gz_encode_kernel
+// =================================================================================================================
+__global__ __launch_bounds__(WAVE * WPB) void gz_encode_kernel(GzDeviceTables T, GzEncodeArgs A)
+{
+    __shared__ WaveLds lds[WPB];
+    const int lane = lane_id();
+    const int wv = threadIdx.x / WAVE;
+    const int64_t d = (int64_t)blockIdx.x * WPB + wv;
+    if (d >= A.n_docs) return;
+    if (A.huge_pass && A.n_real[d] != GZ_DEFERRED) return;
+    WaveLds& L = lds[wv];
+
+    const int64_t a0 = A.text_off[d], a1 = A.text_off[d + 1];
+    const int64_t a_end = A.text_off[A.n_docs];
+    int64_t p0 = 0, p1 = 0, p_end = 0;
+    if (A.pair) { p0 = A.pair_off[d]; p1 = A.pair_off[d + 1]; p_end = A.pair_off[A.n_docs]; }
+
+    Emit E;
+    E.symout = nullptr;
+    E.pad_id = T.pad_id;
+    E.ntok = 0;
+    if (A.dense) {
+        E.ids = A.ids + d * (int64_t)A.max_len;
+        E.mask = A.mask + d * (int64_t)A.max_len;
+        E.limit = A.max_len - 1;                    // position max_len-1 is eos or padding, never a raw token
+        E.stop = A.max_len;
+    } else {
+        // raw row in the workspace: at most bytes+2 tokens per text
+        const int64_t ro = (a0 - A.text_off[0]) + 2 * d + (A.pair ? (p0 - A.pair_off[0]) + 2 * d : 0);
+        E.ids = A.raw + ro;
+        E.mask = nullptr;
+        E.limit = 0x7FFFFFFF;
+        E.stop = 0x7FFFFFFF;
+    }
+    uint32_t* arenaA = A.arena;
+    uint32_t* arenaB = A.arena ? A.arena + (a_end - A.text_off[0]) - (A.pair ? A.pair_off[0] : 0) : nullptr;
+
+    bool ok = true;
+    emit_uniform(E, T.bos_id, lane);                                          // tokenize.py:134-135
+    ok = encode_text(T, L, A.text, a0, a1, a_end, arenaA ? arenaA - A.text_off[0] : nullptr, E, lane);
+    if (ok) {
+        emit_uniform(E, T.eos_id, lane);
+        if (A.pair) {                                                         // tokenize.py:237-239
+            emit_uniform(E, T.eos_id, lane);
+            if (E.ntok < E.stop) ok = encode_text(T, L, A.pair, p0, p1, p_end, arenaB, E, lane);
+            if (ok) emit_uniform(E, T.eos_id, lane);
+        }
+    }
+    if (!ok) {
+        if (lane == 0) { A.n_real[d] = GZ_DEFERRED; *A.defer_flag = 1; }
+        return;
+    }
+    if (A.dense) {
+        // __padding (tokenize.py:141-146) + attention mask (:148-152)
+        const int Lm = A.max_len;
+        const int t = E.ntok < Lm ? E.ntok : Lm;
+        const bool cut = E.ntok >= Lm;
+        for (int i = (cut ? Lm - 1 : t) + lane; i < Lm; i += WAVE) {
+            const int32_t v = cut ? T.eos_id : T.pad_id;
+            E.ids[i] = v;
+            E.mask[i] = v != T.pad_id ? 1 : 0;
+        }
+        if (lane == 0) A.n_real[d] = t;
+    } else if (lane == 0) {
+        A.n_real[d] = E.ntok;
+    }
+}
+
+// =================================================================================================================
+// Ragged layouts: row length, scan, finalize
+// =================================================================================================================
+__device__ __forceinline__ int cut_len(int n, int max_len)            // len(seq[:max_len-1])
+{
+    const int stop = max_len - 1;
+    if (stop >= 0) return n < stop ? n : stop;
+    const int k = n + stop;
+    return k > 0 ? k : 0;
+}
+
+__device__ __forceinline__ int padded_len(int n, const GzShape& S)   // len(__padding(seq)) when it applies
+{
+    if (!S.pad_mode) return n;
+    if (n < S.max_len) return S.max_len;
+    if (S.truncation) return cut_len(n, S.max_len) + 1;
+    return n;
+}
+
+__global__ void gz_rowlen_kernel(const int32_t* n_raw, int64_t n_docs, GzShape S, int64_t* row_len)
+{
+    const int64_t d = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d < n_docs) row_len[d] = padded_len(n_raw[d], S);
+}
+
+// single-workgroup exclusive scan of int64 (ragged layouts only; N/1024 trips)
+__global__ __launch_bounds__(1024) void gz_scan_kernel(const int64_t* in, int64_t n, int64_t* out /* n+1 */)
+{
+    __shared__ int64_t wsum[16];
+    __shared__ int64_t carry;
+    const int lane = lane_id(), wv = threadIdx.x / WAVE;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int64_t base = 0; base < n; base += 1024) {
+        const int64_t i = base + threadIdx.x;
+        const int64_t v = i < n ? in[i] : 0;
+        int64_t x = v;
+#pragma unroll
+        for (int dlt = 1; dlt < WAVE; dlt <<= 1) {
+            const int64_t y = __shfl_up(x, dlt, WAVE);
+            if (lane >= dlt) x += y;
+        }
+        if (lane == WAVE - 1) wsum[wv] = x;
+        __syncthreads();
+        int64_t pre = carry;
+        for (int k = 0; k < wv; ++k) pre += wsum[k];
+        if (i < n) out[i] = pre + x - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = pre + x;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) out[n] = carry;
+}
+
+__global__ __launch_bounds__(WAVE * WPB) void gz_finalize_kernel(GzDeviceTables T, GzFinalizeArgs F)
+{
+    const int lane = lane_id();
+    const int64_t d = (int64_t)blockIdx.x * WPB + threadIdx.x / WAVE;
+    if (d >= F.n_docs) return;
+    if (F.row_off[F.n_docs] > F.capacity) {
+        if (d == 0 && lane == 0) *F.error_flag = 1;
+        return;
+    }
+    const int64_t ro = (F.text_off[d] - F.text_off[0]) + 2 * d + (F.pair_off ? (F.pair_off[d] - F.pair_off[0]) + 2 * d : 0);
+    const int32_t* raw = F.raw + ro;
+    const int n = F.n_raw[d];
+    const int64_t o = F.row_off[d];
+    const int R = (int)(F.row_off[d + 1] - o);
+    const bool padded = F.S.pad_mode && n < F.S.max_len;
+    const bool cut = F.S.pad_mode && !padded && F.S.truncation;
+    const int kept = cut ? R - 1 : n;
+    for (int i = lane; i < R; i += WAVE) {
+        int32_t v;
+        if (i < kept) v = raw[i];
+        else v = cut ? T.eos_id : T.pad_id;
+        F.ids[o + i] = v;
+        F.mask[o + i] = v != T.pad_id ? 1 : 0;
+    }
+    if (lane == 0) F.n_real[d] = padded ? n : R;
+}
+
+// =================================================================================================================
+// gz_pair_kernel: get_sequence_id (tokenize.py:163-182), get_token_type (:154-161), __padding of it (:256-258)
+// =================================================================================================================
+__global__ __launch_bounds__(WAVE * WPB) void gz_pair_kernel(GzDeviceTables T, GzPairArgs P)
+{
+    const int lane = lane_id();
+    const int64_t d = (int64_t)blockIdx.x * WPB + threadIdx.x / WAVE;
+    if (d >= P.n_docs) return;
+    if (P.row_off && P.row_off[P.n_docs] > P.capacity) return;
+    const int64_t o = P.row_off ? P.row_off[d] : d * (int64_t)P.S.max_len;
+    const int R = P.row_off ? (int)(P.row_off[d + 1] - o) : P.S.max_len;
+    const int32_t* ids = P.ids + o;
+    const int32_t eos = T.eos_id, bos = T.bos_id;
+
+    // p1: first eos (the loop at :168-173 stops there)
+    int p1 = R;
+    for (int base = 0; base < R; base += WAVE) {
+        const int i = base + lane;
+        const uint64_t m = __ballot(i < R && ids[i] == eos);
+        if (m) { p1 = base + __ffsll((unsigned long long)m) - 1; break; }
+    }
+    // p2: first eos after p1 that directly follows a `1` entry (:176-179) -> the list ends there
+    int seq_len = R;
+    for (int base = (p1 + 2) & ~(WAVE - 1); base < R; base += WAVE) {
+        const int i = base + lane;
+        const bool hit = i < R && i >= p1 + 2 && ids[i] == eos && ids[i - 1] != eos;
+        const uint64_t m = __ballot(hit);
+        if (m) { seq_len = base + __ffsll((unsigned long long)m) - 1 + 1; break; }
+    }
+    auto raw_val = [&](int i) -> int32_t {                     // the list before get_token_type touches it
+        const int32_t v = ids[i];
+        if (i < p1) return v == bos ? GZ_NONE_ : 0;
+        if (i == p1) return GZ_NONE_;
+        return v == eos ? GZ_NONE_ : 1;
+    };
+    // get_token_type: [0]=0, [-1]=1, then the first two remaining None -> 0, 1
+    int n1 = -1, n2 = -1;
+    for (int base = 0; base < seq_len && n2 < 0; base += WAVE) {
+        const int i = base + lane;
+        const bool none = i > 0 && i < seq_len - 1 && raw_val(i) == GZ_NONE_;
+        uint64_t m = __ballot(none);
+        while (m && n2 < 0) {
+            const int p = base + __ffsll((unsigned long long)m) - 1;
+            if (n1 < 0) n1 = p; else n2 = p;
+            m &= m - 1;
+        }
+    }
+    const bool bad = n2 < 0;                                   // list.index(None) raises ValueError
+    if (lane == 0) P.status[d] = bad ? 1 : 0;
+    auto final_val = [&](int i) -> int32_t {
+        if (i == seq_len - 1) return 1;
+        if (i == 0) return 0;
+        if (i == n1) return 0;
+        if (i == n2) return 1;
+        return raw_val(i);
+    };
+    int tt_len = seq_len;
+    bool tt_pad = false, tt_cut = false;
+    if (P.S.pad_mode) {
+        if (seq_len < P.S.max_len) { tt_len = P.S.max_len; tt_pad = true; }
+        else if (P.S.truncation) { tt_len = cut_len(seq_len, P.S.max_len) + 1; tt_cut = true; }
+    }
+    if (lane == 0) { P.pair_len[2 * d] = bad ? 0 : seq_len; P.pair_len[2 * d + 1] = bad ? 0 : tt_len; }
+    if (bad) return;
+    for (int i = lane; i < seq_len; i += WAVE) P.seq[o + i] = final_val(i);
+    const int kept = tt_cut ? tt_len - 1 : seq_len;
+    for (int i = lane; i < tt_len; i += WAVE) {
+        int32_t v;
+        if (i < kept) v = final_val(i);
+        else v = tt_cut ? eos : T.pad_id;
+        (void)tt_pad;
+        P.tt[o + i] = v;
+    }
+}
+
+// =================================================================================================================
+// gz_bpe_word_kernel: Tokenize.bpe(token) -- the whole input is ONE word (no whitespace split, no glue)
+// =================================================================================================================
+__global__ __launch_bounds__(WAVE) void gz_bpe_word_kernel(GzDeviceTables T, const uint8_t* word, int64_t nbytes,
+                                                            uint32_t* arena, int32_t* out, int32_t cap, int32_t* n_out)
+{
+    __shared__ WaveLds L;
+    const int lane = lane_id();
+    Emit E;
+    E.ids = nullptr; E.mask = nullptr; E.symout = out; E.limit = cap; E.stop = 0x7FFFFFFF; E.ntok = 0; E.pad_id = T.pad_id;
+    long_word(T, L, word, nbytes, false, arena, E, lane);
+    if (lane == 0) *n_out = E.ntok;
+}
+
+// =================================================================================================================
+// launchers
+// =================================================================================================================
+void gz_launch_encode(const GzDeviceTables& T, const GzEncodeArgs& A, hipStream_t s)
+{
+    const int64_t blocks = (A.n_docs + WPB - 1) / WPB;
+    if (blocks > 0) hipLaunchKernelGGL(gz_encode_kernel, dim3((unsigned)blocks), dim3(WAVE * WPB), 0, s, T, A);
+}
+
+void gz_launch_rowscan(const GzFinalizeArgs& F, int64_t* row_len_tmp, hipStream_t s)
+{
+    if (F.n_docs <= 0) return;
+    hipLaunchKernelGGL(gz_rowlen_kernel, dim3((unsigned)((F.n_docs + 255) / 256)), dim3(256), 0, s,
+                       F.n_raw, F.n_docs, F.S, row_len_tmp);
+    hipLaunchKernelGGL(gz_scan_kernel, dim3(1), dim3(1024), 0, s, (const int64_t*)row_len_tmp, F.n_docs, F.row_off);
+}
+
+void gz_launch_finalize(const GzDeviceTables& T, const GzFinalizeArgs& F, hipStream_t s)
+{
+    if (F.n_docs <= 0) return;
+    hipLaunchKernelGGL(gz_finalize_kernel, dim3((unsigned)((F.n_docs + WPB - 1) / WPB)), dim3(WAVE * WPB), 0, s, T, F);
+}
+
+void gz_launch_pair(const GzDeviceTables& T, const GzPairArgs& P, hipStream_t s)
+{
+    if (P.n_docs <= 0) return;
+    hipLaunchKernelGGL(gz_pair_kernel, dim3((unsigned)((P.n_docs + WPB - 1) / WPB)), dim3(WAVE * WPB), 0, s, T, P);
+}
+
+void gz_launch_bpe_word(const GzDeviceTables& T, const uint8_t* word, int64_t nbytes, uint32_t* arena,
+                        int32_t* out, int32_t cap, int32_t* n_out, hipStream_t s)
+{
+    hipLaunchKernelGGL(gz_bpe_word_kernel, dim3(1), dim3(WAVE), 0, s, T, word, nbytes, arena, out, cap, n_out);
+}

@@ -1,0 +1,336 @@
+"""ctypes binding of include/genz_tokenize.h (libgenz_tokenize_hip.so).
+
+Thin by design: argument marshalling only.  There is no CPU fallback -- if the
+shared library is missing or no gfx950 device is usable, constructing a context
+raises RuntimeError.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgenz_tokenize_hip.so")
+
+GZ_OK, GZ_E_INVALID, GZ_E_UTF8, GZ_E_HIP, GZ_E_NOTABLES = 0, -1, -2, -3, -4
+GZ_E_CAPACITY, GZ_E_LIMIT, GZ_E_NOMEM, GZ_E_RCCL, GZ_E_NODEVICE = -5, -6, -7, -8, -9
+GZ_PADDING, GZ_TRUNCATION, GZ_MAX_LEN_NONE, GZ_TIMING = 0x1, 0x2, 0x4, 0x100
+GZ_NONE = -1
+
+# every symbol include/genz_tokenize.h declares (tests/test_abi.py checks the export list against the header)
+SYMBOLS = [
+    "gz_version", "gz_create", "gz_destroy", "gz_last_error", "gz_load_tables", "gz_table_info",
+    "gz_vocab_entry", "gz_merge_entry", "gz_encode_batch", "gz_encode_batch_device", "gz_sync",
+    "gz_bpe_word", "gz_symbol_utf8", "gz_device_alloc", "gz_device_free", "gz_memcpy_h2d", "gz_memcpy_d2h",
+    "gz_timing", "gz_comm_unique_id", "gz_comm_init", "gz_gather_rows",
+    "gz_host_tables_create", "gz_host_tables_destroy", "gz_host_tables_array", "gz_host_tables_vocab_entry",
+    "gz_host_tables_merge_entry", "gz_host_tables_symbol",
+]
+
+_lib = None
+
+
+class GzError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("genz_tokenize (HIP): error %d: %s" % (code, msg))
+        self.code = code
+
+
+def load_library():
+    """dlopen the C-ABI library and declare its prototypes.  Raises RuntimeError when it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "genz_tokenize: %s is missing -- build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C genz-tokenize_amd/csrc`.  There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, u32, sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_size_t
+    P = C.POINTER
+    L.gz_version.restype = C.c_int
+    L.gz_create.argtypes = [C.c_int, P(vp)]
+    L.gz_destroy.argtypes = [vp]; L.gz_destroy.restype = None
+    L.gz_last_error.argtypes = [vp]; L.gz_last_error.restype = C.c_char_p
+    L.gz_load_tables.argtypes = [vp, vp, sz, vp, sz, P(C.c_char_p)]
+    L.gz_table_info.argtypes = [vp, P(i32), P(i32), P(i32), P(i32)]
+    L.gz_vocab_entry.argtypes = [vp, i64, P(vp), P(i32), P(i32)]
+    L.gz_merge_entry.argtypes = [vp, i64, P(vp), P(i32), P(i32), P(i32)]
+    enc = [vp, vp, vp, vp, vp, i64, i32, u32, i64, vp, vp, vp, vp, vp, vp, vp, vp]
+    L.gz_encode_batch.argtypes = enc
+    L.gz_encode_batch_device.argtypes = enc
+    L.gz_sync.argtypes = [vp]
+    L.gz_bpe_word.argtypes = [vp, vp, i64, vp, i64]; L.gz_bpe_word.restype = i64
+    L.gz_symbol_utf8.argtypes = [vp, i32, P(vp), P(i32)]
+    L.gz_device_alloc.argtypes = [vp, sz, P(vp)]
+    L.gz_device_free.argtypes = [vp, vp]
+    L.gz_memcpy_h2d.argtypes = [vp, vp, vp, sz]
+    L.gz_memcpy_d2h.argtypes = [vp, vp, vp, sz]
+    L.gz_timing.argtypes = [vp, P(C.c_double)]
+    L.gz_comm_unique_id.argtypes = [vp]
+    L.gz_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
+    L.gz_gather_rows.argtypes = [vp, vp, i64, i32, vp, vp, C.c_int]
+    L.gz_host_tables_create.argtypes = [vp, sz, vp, sz, P(C.c_char_p), P(vp)]
+    L.gz_host_tables_destroy.argtypes = [vp]; L.gz_host_tables_destroy.restype = None
+    L.gz_host_tables_array.argtypes = [vp, C.c_int, P(vp), P(i64)]
+    L.gz_host_tables_vocab_entry.argtypes = [vp, i64, P(vp), P(i32), P(i32)]
+    L.gz_host_tables_merge_entry.argtypes = [vp, i64, P(vp), P(i32), P(i32), P(i32)]
+    L.gz_host_tables_symbol.argtypes = [vp, i32, P(vp), P(i32)]
+    for name in SYMBOLS:
+        fn = getattr(L, name)
+        if name not in ("gz_destroy", "gz_last_error", "gz_bpe_word", "gz_host_tables_destroy"):
+            fn.restype = C.c_int
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return None if a is None else C.c_void_p(a.ctypes.data)
+
+
+def default_device() -> int:
+    for k in ("GENZ_TOKENIZE_DEVICE", "LOCAL_RANK"):
+        v = os.environ.get(k)
+        if v is not None and v.strip() != "":
+            return int(v)
+    return 0
+
+
+class Context:
+    """One gz_ctx: one GPU, one set of tables."""
+
+    def __init__(self, device: int | None = None):
+        self.lib = load_library()
+        self.handle = C.c_void_p()
+        self.device = default_device() if device is None else int(device)
+        rc = self.lib.gz_create(self.device, C.byref(self.handle))
+        if rc != GZ_OK:
+            msg = self.lib.gz_last_error(None).decode("utf-8", "replace")
+            self.handle = C.c_void_p()
+            raise RuntimeError("genz_tokenize: cannot create a HIP context on device %d (%d: %s). "
+                               "This build has no CPU fallback." % (self.device, rc, msg))
+
+    def close(self):
+        if getattr(self, "handle", None) is not None and self.handle.value:
+            self.lib.gz_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+    def _check(self, rc):
+        if rc < 0:
+            raise GzError(rc, self.lib.gz_last_error(self.handle).decode("utf-8", "replace"))
+        return rc
+
+    # ---- tables ------------------------------------------------------------------------------------------
+    def load_tables(self, vocab: bytes, bpe: bytes, specials):
+        arr = (C.c_char_p * 5)(*[s.encode("utf-8", "surrogatepass") for s in specials])
+        vb = C.create_string_buffer(vocab, len(vocab)) if vocab else None
+        bb = C.create_string_buffer(bpe, len(bpe)) if bpe else None
+        self._check(self.lib.gz_load_tables(self.handle, C.cast(vb, C.c_void_p) if vb else None, len(vocab),
+                                            C.cast(bb, C.c_void_p) if bb else None, len(bpe), arr))
+
+    def table_info(self):
+        vs, nr, ns = C.c_int32(), C.c_int32(), C.c_int32()
+        sp = (C.c_int32 * 5)()
+        self._check(self.lib.gz_table_info(self.handle, C.byref(vs), sp, C.byref(nr), C.byref(ns)))
+        return vs.value, list(sp), nr.value, ns.value
+
+    def vocab_items(self):
+        n = self.table_info()[0]
+        p, ln, idv = C.c_void_p(), C.c_int32(), C.c_int32()
+        out = []
+        for i in range(n):
+            self._check(self.lib.gz_vocab_entry(self.handle, i, C.byref(p), C.byref(ln), C.byref(idv)))
+            out.append((C.string_at(p, ln.value).decode("utf-8"), idv.value))
+        return out
+
+    def merge_items(self):
+        n = self.table_info()[2]
+        p, ln, nf, rk = C.c_void_p(), C.c_int32(), C.c_int32(), C.c_int32()
+        out = []
+        for i in range(n):
+            self._check(self.lib.gz_merge_entry(self.handle, i, C.byref(p), C.byref(ln), C.byref(nf), C.byref(rk)))
+            s = C.string_at(p, ln.value).decode("utf-8")
+            out.append((tuple(s.split("\n")) if nf.value else (), rk.value))
+        return out
+
+    def symbol(self, sym: int) -> str:
+        p, ln = C.c_void_p(), C.c_int32()
+        self._check(self.lib.gz_symbol_utf8(self.handle, sym, C.byref(p), C.byref(ln)))
+        return C.string_at(p, ln.value).decode("utf-8")
+
+    # ---- encode, host buffers ------------------------------------------------------------------------------
+    def encode(self, text: np.ndarray, text_off: np.ndarray, pair, pair_off, max_len, padding, truncation):
+        """Returns dict(input_ids, attention_mask, [token_type_ids, sequence_id, pair_len, status], row_off,
+        n_real, dense).  Flat int32 arrays + int64 row offsets."""
+        n = len(text_off) - 1
+        flags = (GZ_PADDING if padding else 0) | (GZ_TRUNCATION if truncation else 0)
+        ml = 0
+        if max_len is None:
+            flags |= GZ_MAX_LEN_NONE
+        else:
+            ml = int(max_len)
+            if not -2**31 <= ml < 2**31:
+                raise OverflowError("max_len does not fit in int32")
+        is_pair = pair_off is not None
+        dense = bool(max_len is not None and padding and truncation and ml >= 1)
+        tb = int(text_off[-1] - text_off[0]) if n else 0
+        pb = int(pair_off[-1] - pair_off[0]) if (is_pair and n) else 0
+        if dense:
+            cap = n * ml
+        else:
+            cap = tb + pb + (4 if is_pair else 2) * n
+            if max_len is not None and padding and ml > 0:
+                cap += n * ml
+        ids = np.empty(max(cap, 1), dtype=np.int32)
+        mask = np.empty(max(cap, 1), dtype=np.int32)
+        tt = np.empty(max(cap, 1), dtype=np.int32) if is_pair else None
+        seq = np.empty(max(cap, 1), dtype=np.int32) if is_pair else None
+        row_off = np.zeros(n + 1, dtype=np.int64)
+        pair_len = np.zeros(2 * max(n, 1), dtype=np.int32) if is_pair else None
+        n_real = np.zeros(max(n, 1), dtype=np.int32)
+        status = np.zeros(max(n, 1), dtype=np.int32)
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        text_off = np.ascontiguousarray(text_off, dtype=np.int64)
+        if is_pair:
+            pair = np.ascontiguousarray(pair, dtype=np.uint8)
+            pair_off = np.ascontiguousarray(pair_off, dtype=np.int64)
+        self._check(self.lib.gz_encode_batch(
+            self.handle, _ptr(text), _ptr(text_off), _ptr(pair) if is_pair else None,
+            _ptr(pair_off) if is_pair else None, n, ml, flags, cap, _ptr(ids), _ptr(mask), _ptr(tt), _ptr(seq),
+            _ptr(row_off), _ptr(pair_len), _ptr(n_real), _ptr(status)))
+        total = int(row_off[-1]) if n else 0
+        out = dict(input_ids=ids[:total], attention_mask=mask[:total], row_off=row_off, n_real=n_real[:n],
+                   status=status[:n], dense=dense, max_len=ml)
+        if is_pair:
+            out.update(token_type_ids=tt[:total], sequence_id=seq[:total], pair_len=pair_len[:2 * n].reshape(n, 2))
+        return out
+
+    def bpe_word(self, word: bytes):
+        cap = len(word) + 1
+        out = np.empty(cap, dtype=np.int32)
+        buf = np.frombuffer(word, dtype=np.uint8)
+        n = self.lib.gz_bpe_word(self.handle, _ptr(buf), len(word), _ptr(out), cap)
+        self._check(n)
+        return out[:n]
+
+    # ---- device-resident path (bench, multi-GPU) ---------------------------------------------------------------
+    def alloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        self._check(self.lib.gz_device_alloc(self.handle, nbytes, C.byref(p)))
+        return p.value
+
+    def free(self, dptr: int):
+        self._check(self.lib.gz_device_free(self.handle, C.c_void_p(dptr)))
+
+    def h2d(self, dptr: int, arr: np.ndarray):
+        arr = np.ascontiguousarray(arr)
+        self._check(self.lib.gz_memcpy_h2d(self.handle, C.c_void_p(dptr), _ptr(arr), arr.nbytes))
+
+    def d2h(self, arr: np.ndarray, dptr: int):
+        assert arr.flags["C_CONTIGUOUS"]
+        self._check(self.lib.gz_memcpy_d2h(self.handle, _ptr(arr), C.c_void_p(dptr), arr.nbytes))
+
+    def encode_device(self, d_text, d_text_off, d_pair, d_pair_off, n_docs, max_len, flags, capacity,
+                      d_ids, d_mask, d_tt=None, d_seq=None, d_row_off=None, d_pair_len=None, d_n_real=None,
+                      d_status=None):
+        vp = C.c_void_p
+        self._check(self.lib.gz_encode_batch_device(
+            self.handle, vp(d_text), vp(d_text_off), vp(d_pair) if d_pair else None,
+            vp(d_pair_off) if d_pair_off else None, n_docs, max_len, flags, capacity, vp(d_ids), vp(d_mask),
+            vp(d_tt) if d_tt else None, vp(d_seq) if d_seq else None, vp(d_row_off) if d_row_off else None,
+            vp(d_pair_len) if d_pair_len else None, vp(d_n_real) if d_n_real else None,
+            vp(d_status) if d_status else None))
+
+    def sync(self):
+        self._check(self.lib.gz_sync(self.handle))
+
+    def timing(self):
+        t = (C.c_double * 4)()
+        self._check(self.lib.gz_timing(self.handle, t))
+        return list(t)
+
+    # ---- RCCL ---------------------------------------------------------------------------------------------------
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        self._check(self.lib.gz_comm_unique_id(C.cast(buf, C.c_void_p)))
+        return buf.raw
+
+    def comm_init(self, uid: bytes, rank: int, world: int):
+        buf = C.create_string_buffer(uid, 128)
+        self._check(self.lib.gz_comm_init(self.handle, C.cast(buf, C.c_void_p), rank, world))
+
+    def gather_rows(self, d_send, n_rows_local, row_len, d_recv, rows_per_rank, root=0):
+        rpr = np.ascontiguousarray(rows_per_rank, dtype=np.int64)
+        self._check(self.lib.gz_gather_rows(self.handle, C.c_void_p(d_send), n_rows_local, row_len,
+                                            C.c_void_p(d_recv) if d_recv else None, _ptr(rpr), root))
+
+
+class HostTables:
+    """gz_host_tables: the loader + table builder run on the host only (no GPU).  Used by the CPU test-suite to
+    check the integer tables the kernels consume, and by tools that want to inspect them."""
+
+    _DT = {0: (np.uint64, 1), 1: (np.uint32, 4), 2: (np.int32, 2), 3: (np.uint32, 2), 4: (np.uint32, 4), 5: (np.int32, 1)}
+
+    def __init__(self, vocab: bytes, bpe: bytes, specials=("<pad>", "<s>", "</s>", "<mask>", "<unk>")):
+        self.lib = load_library()
+        self.handle = C.c_void_p()
+        arr = (C.c_char_p * 5)(*[s.encode("utf-8", "surrogatepass") for s in specials])
+        vb = C.create_string_buffer(vocab, len(vocab)) if vocab else None
+        bb = C.create_string_buffer(bpe, len(bpe)) if bpe else None
+        rc = self.lib.gz_host_tables_create(C.cast(vb, C.c_void_p) if vb else None, len(vocab),
+                                            C.cast(bb, C.c_void_p) if bb else None, len(bpe), arr, C.byref(self.handle))
+        if rc != GZ_OK:
+            raise GzError(rc, self.lib.gz_last_error(None).decode("utf-8", "replace"))
+
+    def array(self, which: int) -> np.ndarray:
+        p, n = C.c_void_p(), C.c_int64()
+        rc = self.lib.gz_host_tables_array(self.handle, which, C.byref(p), C.byref(n))
+        if rc != GZ_OK:
+            raise GzError(rc, "gz_host_tables_array")
+        dt, w = self._DT[which]
+        if n.value == 0:
+            return np.zeros((0, w) if w > 1 else 0, dtype=dt)
+        buf = (C.c_char * (n.value * w * np.dtype(dt).itemsize)).from_address(p.value)
+        a = np.frombuffer(buf, dtype=dt).copy()
+        return a.reshape(n.value, w) if w > 1 else a
+
+    def vocab_items(self):
+        out, i = [], 0
+        p, ln, idv = C.c_void_p(), C.c_int32(), C.c_int32()
+        while self.lib.gz_host_tables_vocab_entry(self.handle, i, C.byref(p), C.byref(ln), C.byref(idv)) == GZ_OK:
+            out.append((C.string_at(p, ln.value).decode("utf-8"), idv.value)); i += 1
+        return out
+
+    def merge_items(self):
+        out, i = [], 0
+        p, ln, nf, rk = C.c_void_p(), C.c_int32(), C.c_int32(), C.c_int32()
+        while self.lib.gz_host_tables_merge_entry(self.handle, i, C.byref(p), C.byref(ln), C.byref(nf), C.byref(rk)) == GZ_OK:
+            s = C.string_at(p, ln.value).decode("utf-8")
+            out.append((tuple(s.split("\n")) if nf.value else (), rk.value)); i += 1
+        return out
+
+    def symbols(self):
+        out, i = [], 0
+        p, ln = C.c_void_p(), C.c_int32()
+        while self.lib.gz_host_tables_symbol(self.handle, i, C.byref(p), C.byref(ln)) == GZ_OK:
+            out.append(C.string_at(p, ln.value).decode("utf-8")); i += 1
+        return out
+
+    def close(self):
+        if self.handle.value:
+            self.lib.gz_host_tables_destroy(self.handle)
+            self.handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass

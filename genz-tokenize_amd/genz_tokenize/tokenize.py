@@ -1,0 +1,264 @@
+"""Drop-in `Tokenize` for DVNghiem/genz-tokenize v1.2.7, computed on an MI355X.
+
+Same Python surface as the reference class (reference genz_tokenize/tokenize.py:6-278):
+`Tokenize(...)`, `Tokenize.fromFile`, `__call__`, `encode`, `decode`, `bpe`, `vocab_size`,
+`add_vocab_file`, `add_bpe_file`, the three `get_*` helpers and the module function
+`get_pairs`, with the same results, key order, `None`s and exceptions.  Underneath, every
+call that tokenizes goes through the C ABI of include/genz_tokenize.h into hand-written HIP
+kernels; nothing here falls back to a CPU implementation.
+
+On top of the reference surface there is a batch API (`encode_batch`, `encode_packed`)
+that returns numpy arrays, which is what the GPU is for.
+"""
+from __future__ import annotations
+
+import os
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+from . import _native
+
+_DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+
+
+def _read_text(path) -> str:
+    # the reference opens both files with open(path, 'r', encoding='utf-8') (tokenize.py:45, :54):
+    # FileNotFoundError / UnicodeDecodeError surface from here exactly as they do there
+    with open(path, "r", encoding="utf-8") as f:
+        return f.read()
+
+
+def _require_str(x):
+    # re.findall(r"\S+\n?", x) (tokenize.py:106) is what rejects non-str input in the reference
+    if isinstance(x, str):
+        return
+    if isinstance(x, (bytes, bytearray, memoryview)):
+        raise TypeError("cannot use a string pattern on a bytes-like object")
+    raise TypeError("expected string or bytes-like object")
+
+
+def _pack(texts: Sequence[str]):
+    parts = []
+    off = np.zeros(len(texts) + 1, dtype=np.int64)
+    for i, t in enumerate(texts):
+        _require_str(t)
+        b = t.encode("utf-8", "surrogatepass")
+        parts.append(b)
+        off[i + 1] = off[i] + len(b)
+    buf = np.frombuffer(b"".join(parts), dtype=np.uint8) if off[-1] else np.zeros(0, dtype=np.uint8)
+    return buf, off
+
+
+class Tokenize(object):
+    def __init__(self, pad_token='<pad>', bos_token='<s>', eos_token='</s>', mask_token='<mask>',
+                 unk_token='<unk>', device: Optional[int] = None) -> None:
+        super().__init__()
+        # tokenize.py:15-23 -- paths survive a second __init__ (that is how fromFile works)
+        if not hasattr(self, "vocab_file"):
+            self.vocab_file = os.path.join(_DATA, "vocab.txt")
+        if not hasattr(self, "bpe_file"):
+            self.bpe_file = os.path.join(_DATA, "bpe.codes")
+        self.pad_token, self.bos_token, self.eos_token = pad_token, bos_token, eos_token
+        self.mask_token, self.unk_token = mask_token, unk_token
+        if not hasattr(self, "_ctx"):
+            self._ctx = _native.Context(device)
+        self._vocab_texts: List[str] = []
+        self._bpe_text = ""
+        self._dicts = {}
+        self._dirty = True
+        self.add_vocab_file(self.vocab_file)
+        self._decoder_snapshot = None           # tokenize.py:40: decoder is built once, after the first vocab load
+        self._sync_tables()
+        self._decoder_snapshot = {v: k for k, v in self.encoder.items()}
+        self.add_bpe_file(self.bpe_file)
+
+    # ---- tables -------------------------------------------------------------------------------------------
+    def add_vocab_file(self, vocab_file):
+        """tokenize.py:44-51 -- appends words to `encoder`; the device tables are rebuilt lazily."""
+        self._vocab_texts.append(_read_text(vocab_file))
+        self._dirty = True
+
+    def add_bpe_file(self, bpe_file):
+        """tokenize.py:53-57 -- replaces `bpe_ranks`."""
+        self._bpe_text = _read_text(bpe_file)
+        self._dirty = True
+
+    def _sync_tables(self):
+        if not self._dirty:
+            return
+        # several vocab files behave like one file whose lines are the concatenation of theirs
+        chunks = []
+        for t in self._vocab_texts:
+            chunks.append(t if (t == "" or t.endswith("\n")) else t + "\n")
+        vocab = "".join(chunks).encode("utf-8")
+        self._ctx.load_tables(vocab, self._bpe_text.encode("utf-8"),
+                              (self.pad_token, self.bos_token, self.eos_token, self.mask_token, self.unk_token))
+        self._dicts = {}
+        self._dirty = False
+
+    @property
+    def encoder(self) -> Dict[str, int]:
+        self._sync_tables()
+        if "encoder" not in self._dicts:
+            self._dicts["encoder"] = dict(self._ctx.vocab_items())
+        return self._dicts["encoder"]
+
+    @property
+    def decoder(self) -> Dict[int, str]:
+        return self._decoder_snapshot
+
+    @property
+    def bpe_ranks(self):
+        self._sync_tables()
+        if "ranks" not in self._dicts:
+            self._dicts["ranks"] = dict(self._ctx.merge_items())
+        return self._dicts["ranks"]
+
+    def vocab_size(self):
+        self._sync_tables()
+        return self._ctx.table_info()[0]
+
+    def _special_ids(self):
+        self._sync_tables()
+        return self._ctx.table_info()[1]       # pad, bos, eos, mask, unk  (looked up at call time, rule L4)
+
+    # ---- BPE of one word -----------------------------------------------------------------------------------
+    def bpe(self, token):
+        """tokenize.py:62-101: "piece@@ piece ..." for ONE word (no whitespace splitting here)."""
+        if not isinstance(token, str):
+            raise TypeError("bpe() expects str")
+        if token == "":
+            raise IndexError("tuple index out of range")         # word[-1] on an empty tuple (tokenize.py:64)
+        self._sync_tables()
+        pieces = self._ctx.bpe_word(token.encode("utf-8", "surrogatepass"))
+        if len(pieces) == 1 and len(token) == 1:
+            return token                                         # tokenize.py:66-67
+        strs = []
+        for k, p in enumerate(pieces):
+            p = int(p)
+            if p >= 0:
+                strs.append(self._ctx.symbol(p))
+            else:
+                strs.append(chr(-p - 1) + ("</w>" if k == len(pieces) - 1 else ""))
+        return "@@ ".join(strs)[:-4]
+
+    # ---- encode / decode -------------------------------------------------------------------------------------
+    def _run(self, texts, pairs, max_len, padding, truncation):
+        self._sync_tables()
+        tb, to = _pack(texts)
+        pb = po = None
+        if pairs is not None:
+            pb, po = _pack(pairs)
+        return self._ctx.encode(tb, to, pb, po, max_len, bool(padding), bool(truncation))
+
+    def encode(self, sentence, return_offset) -> List[int]:
+        """tokenize.py:126-135."""
+        _require_str(sentence)
+        if return_offset:
+            raise NotImplementedError("return_offset is not implemented on the HIP path yet (SURVEY.md 8(f) row 1)")
+        r = self._run([sentence], None, None, False, False)
+        return r["input_ids"].tolist()
+
+    def decode(self, token):
+        """tokenize.py:137-139 (host side: string assembly)."""
+        dec, unk = self.decoder, self.unk_token
+        return ' '.join(dec.get(i, unk) for i in token).replace('@@ ', '')
+
+    def get_atttention_mask(self, token):
+        pad = self._special_ids()[0]
+        return [1 if i != pad else 0 for i in token]
+
+    def get_token_type(self, token):
+        """tokenize.py:154-161 (mutates and returns its argument; ValueError when < 2 None remain)."""
+        token[0] = 0
+        token[-1] = 1
+        token[token.index(None)] = 0
+        token[token.index(None)] = 1
+        return token
+
+    def get_sequence_id(self, token):
+        """tokenize.py:163-182."""
+        sp = self._special_ids()
+        bos, eos = sp[1], sp[2]
+        out = []
+        for v in token:
+            if v == eos:
+                out.append(None)
+                break
+            out.append(None if v == bos else 0)
+        for k in range(len(out), len(token)):
+            if token[k] == eos:
+                out.append(None)
+                if out[k - 1] == 1:
+                    break
+            else:
+                out.append(1)
+        return out
+
+    def __call__(self, text: str, pair_text: str = None, max_len: int = None, padding: bool = True,
+                 truncation: bool = True, return_offset: bool = False) -> Dict:
+        """tokenize.py:184-259.  Returns {'input_ids', 'attention_mask'[, 'sequence_id', 'token_type_ids']}."""
+        _require_str(text)
+        if pair_text is not None:
+            _require_str(pair_text)
+        if return_offset:
+            raise NotImplementedError("return_offset is not implemented on the HIP path yet (SURVEY.md 8(f) row 1)")
+        if max_len is not None and not isinstance(max_len, (int, np.integer)):
+            raise TypeError("max_len must be an int or None")
+        r = self._run([text], None if pair_text is None else [pair_text], max_len, padding, truncation)
+        if pair_text is not None and int(r["status"][0]) != 0:
+            raise ValueError("None is not in list")                 # tokenize.py:157-160, rule P3
+        result = {'input_ids': r["input_ids"].tolist(), 'attention_mask': r["attention_mask"].tolist()}
+        if pair_text is not None:
+            ns, nt = (int(x) for x in r["pair_len"][0])
+            seq = [None if v == _native.GZ_NONE else v for v in r["sequence_id"][:ns].tolist()]
+            if max_len is not None and padding:
+                tt = [None if v == _native.GZ_NONE else v for v in r["token_type_ids"][:nt].tolist()]
+            else:
+                tt = seq                                             # the same list object (tokenize.py:254-255)
+            result['sequence_id'] = seq
+            result['token_type_ids'] = tt
+        return result
+
+    # ---- batch API (new) -----------------------------------------------------------------------------------------
+    def encode_batch(self, texts: Sequence[str], pair_texts: Optional[Sequence[str]] = None,
+                     max_len: Optional[int] = None, padding: bool = True, truncation: bool = True):
+        """`__call__` over many documents in one launch.  With max_len >= 1, padding and truncation the result
+        arrays are [N, max_len] int32; otherwise they are flat with `row_off` [N+1].  `status[i] == 1` marks a
+        document for which the single-call API raises ValueError."""
+        if pair_texts is not None and len(pair_texts) != len(texts):
+            raise ValueError("texts and pair_texts differ in length")
+        r = self._run(list(texts), None if pair_texts is None else list(pair_texts), max_len, padding, truncation)
+        return self._shape(r, len(texts))
+
+    def encode_packed(self, text_u8: np.ndarray, offsets: np.ndarray, pair_u8=None, pair_offsets=None,
+                      max_len: Optional[int] = None, padding: bool = True, truncation: bool = True):
+        """Batch call on already packed UTF-8 (uint8 array + int64 offsets[N+1]); skips Python string packing."""
+        self._sync_tables()
+        r = self._ctx.encode(text_u8, offsets, pair_u8, pair_offsets, max_len, bool(padding), bool(truncation))
+        return self._shape(r, len(offsets) - 1)
+
+    @staticmethod
+    def _shape(r, n):
+        if r["dense"]:
+            L = r["max_len"]
+            for k in ("input_ids", "attention_mask", "token_type_ids", "sequence_id"):
+                if k in r:
+                    r[k] = r[k].reshape(n, L)
+        return r
+
+    @classmethod
+    def fromFile(cls, vocab_file, bpe_file):
+        """tokenize.py:261-267.  (The reference loads the bundled tables first and then re-runs __init__;
+        here the paths are set before the only load.)"""
+        tok = cls.__new__(cls)
+        tok.vocab_file = vocab_file
+        tok.bpe_file = bpe_file
+        tok.__init__()
+        return tok
+
+
+def get_pairs(word):
+    """tokenize.py:270-278: the set of adjacent symbol pairs of a word tuple."""
+    return {(a, b) for a, b in zip(word, word[1:])}

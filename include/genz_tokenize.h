@@ -1,0 +1,165 @@
+/* genz_tokenize.h -- C ABI of the MI355X-native genz-tokenize hot path.
+ *
+ * This is the drop-in boundary underneath the reference's Python surface.  The
+ * reference (DVNghiem/genz-tokenize v1.2.7) is pure Python and has no FFI of its
+ * own, so every entry point below names the reference function it replaces
+ * (paths relative to the reference checkout, genz_tokenize/tokenize.py).
+ *
+ * Conventions
+ *   - plain C types only; the caller owns every buffer it passes in;
+ *   - every function returns GZ_OK (0) or a negative GZ_E_* code; no C++
+ *     exception crosses this boundary; gz_last_error() gives the message;
+ *   - a gz_ctx is bound to ONE GPU (one process per GPU is the multi-GPU model)
+ *     and is not re-entrant; distinct contexts are independent;
+ *   - there is NO CPU fallback: without a usable gfx950 device gz_create fails.
+ *
+ * Text is packed UTF-8: document i is text[text_off[i] .. text_off[i+1]).
+ * Python's `None` inside sequence_id / token_type_ids is carried as GZ_NONE.
+ */
+#ifndef GENZ_TOKENIZE_H
+#define GENZ_TOKENIZE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GZ_VERSION 0x010000
+
+#define GZ_OK            0
+#define GZ_E_INVALID    -1   /* bad argument */
+#define GZ_E_UTF8       -2   /* table file is not valid UTF-8 (reference: UnicodeDecodeError at tokenize.py:45/54) */
+#define GZ_E_HIP        -3   /* HIP runtime error */
+#define GZ_E_NOTABLES   -4   /* gz_load_tables has not succeeded on this context */
+#define GZ_E_CAPACITY   -5   /* ragged output does not fit `capacity`; row_off[n_docs] holds the size needed */
+#define GZ_E_LIMIT      -6   /* table exceeds 2^20-2 symbols or 2^24-1 merge lines */
+#define GZ_E_NOMEM      -7
+#define GZ_E_RCCL       -8
+#define GZ_E_NODEVICE   -9   /* no gfx950 device / HIP runtime unusable */
+
+/* flags of gz_encode_batch*: the keyword arguments of Tokenize.__call__ (tokenize.py:184-190) */
+#define GZ_PADDING       0x1u   /* padding=True                                   */
+#define GZ_TRUNCATION    0x2u   /* truncation=True                                */
+#define GZ_MAX_LEN_NONE  0x4u   /* max_len=None (the max_len argument is ignored) */
+#define GZ_TIMING        0x100u /* record HIP events around the kernels (gz_timing) */
+
+#define GZ_NONE (-1)            /* Python None in sequence_id / token_type_ids */
+
+typedef struct gz_ctx gz_ctx;
+
+int  gz_version(void);
+
+/* Tokenize.__init__ part 1 (tokenize.py:7-37): create a context on HIP device `device_id`. */
+int  gz_create(int device_id, gz_ctx **out);
+void gz_destroy(gz_ctx *ctx);
+const char *gz_last_error(gz_ctx *ctx);   /* ctx may be NULL: error of the last failed gz_create on this thread */
+
+/* add_vocab_file + add_bpe_file (tokenize.py:44-57) on RAW FILE BYTES, followed by the build of the
+ * device-side tables (pair -> rank hash, rank -> merged symbol, symbol -> vocab ids, code point -> symbol).
+ * specials_utf8 = { pad, bos, eos, mask, unk } as NUL-terminated UTF-8 (tokenize.py:7-12, :31-37).
+ * Loader quirks L1-L8 of SURVEY.md are reproduced exactly. */
+int  gz_load_tables(gz_ctx *ctx, const uint8_t *vocab, size_t vocab_len,
+                    const uint8_t *bpe, size_t bpe_len, const char *const specials_utf8[5]);
+
+/* vocab_size() (tokenize.py:59-60), encoder[pad|bos|eos|mask|unk] looked up at call time
+ * (tokenize.py:134,143,145,151,164-165), len(bpe_ranks), number of interned symbols. */
+int  gz_table_info(gz_ctx *ctx, int32_t *vocab_size, int32_t special_ids[5],
+                   int32_t *n_ranks, int32_t *n_symbols);
+
+/* Enumerate the encoder dict built by gz_load_tables in insertion order (so the Python shim can expose
+ * `encoder` / `decoder`, tokenize.py:31-40): entry i -> (utf8 pointer valid until the next gz_load_tables,
+ * byte length, id).  Returns GZ_E_INVALID when i is out of range. */
+int  gz_vocab_entry(gz_ctx *ctx, int64_t i, const uint8_t **utf8, int32_t *len, int32_t *id);
+/* Same for bpe_ranks (tokenize.py:53-57): key i of the dict in insertion order.  The tuple's fields are
+ * returned joined by single '\n' bytes (fields never contain whitespace); n_fields may be 0. */
+int  gz_merge_entry(gz_ctx *ctx, int64_t i, const uint8_t **utf8, int32_t *len, int32_t *n_fields, int32_t *rank);
+
+/* Tokenize.__call__ (tokenize.py:184-259) over a batch of documents, host buffers in, host buffers out.
+ *
+ *   text/text_off          packed UTF-8 and n_docs+1 byte offsets
+ *   pair/pair_off          NULL,NULL -> pair_text=None for every document; otherwise every document is a pair
+ *   max_len, flags         keyword arguments (see GZ_* flags)
+ *
+ * Output layout.  With GZ_PADDING|GZ_TRUNCATION, no GZ_MAX_LEN_NONE and max_len >= 1 every row has exactly
+ * max_len entries ("dense": row i starts at i*max_len, capacity must be >= n_docs*max_len).  Otherwise rows are
+ * ragged: row i occupies [row_off[i], row_off[i+1]) of each flat array; if row_off[n_docs] > capacity nothing is
+ * written to the flat arrays and GZ_E_CAPACITY is returned with row_off filled in.
+ *
+ *   input_ids, attention_mask       always written (tokenize.py:250-251)
+ *   token_type_ids, sequence_id     pair mode only (may be NULL otherwise); both start at row_off[i] like the
+ *                                   input_ids row and never exceed it: sequence_id row i holds pair_len[2i]
+ *                                   entries, token_type_ids row i holds pair_len[2i+1] entries (tokenize.py:252-258;
+ *                                   values 0 / 1 / GZ_NONE / pad id / eos id, rules P1-P6)
+ *   row_off  [n_docs+1]             may be NULL in dense mode
+ *   pair_len [2*n_docs]             pair mode; may be NULL otherwise
+ *   n_real   [n_docs]               entries of the row that are not padding added by rule D1 (may be NULL)
+ *   status   [n_docs]               0 = ok, 1 = the reference raises ValueError("None is not in list") for
+ *                                   this document (tokenize.py:157-160, rule P3); may be NULL in single mode
+ */
+int  gz_encode_batch(gz_ctx *ctx,
+                     const uint8_t *text, const int64_t *text_off,
+                     const uint8_t *pair, const int64_t *pair_off,
+                     int64_t n_docs, int32_t max_len, uint32_t flags, int64_t capacity,
+                     int32_t *input_ids, int32_t *attention_mask,
+                     int32_t *token_type_ids, int32_t *sequence_id,
+                     int64_t *row_off, int32_t *pair_len, int32_t *n_real, int32_t *status);
+
+/* The same call with every pointer a DEVICE pointer on the context's GPU (inputs already resident in HBM,
+ * outputs left in HBM).  Work is enqueued on the context's stream; gz_sync waits for it and returns the
+ * deferred error of the enqueued work, if any.  Only the dense layout and the ragged layout with a
+ * sufficient capacity are available here (GZ_E_CAPACITY is reported by gz_sync). */
+int  gz_encode_batch_device(gz_ctx *ctx,
+                            const uint8_t *text, const int64_t *text_off,
+                            const uint8_t *pair, const int64_t *pair_off,
+                            int64_t n_docs, int32_t max_len, uint32_t flags, int64_t capacity,
+                            int32_t *input_ids, int32_t *attention_mask,
+                            int32_t *token_type_ids, int32_t *sequence_id,
+                            int64_t *row_off, int32_t *pair_len, int32_t *n_real, int32_t *status);
+int  gz_sync(gz_ctx *ctx);
+
+/* Tokenize.bpe(token) (tokenize.py:62-101) for one word: the pieces as interned symbol ids.
+ * pieces[k] >= 0 is a symbol id (string via gz_symbol_utf8); pieces[k] < 0 is -(code point)-1 for a code
+ * point that occurs in no merge and no vocab entry.  Returns the number of pieces or a GZ_E_* code
+ * (GZ_E_CAPACITY if more than `cap`).  The last piece still carries the "</w>" marker. */
+int64_t gz_bpe_word(gz_ctx *ctx, const uint8_t *word_utf8, int64_t len, int32_t *pieces, int64_t cap);
+int  gz_symbol_utf8(gz_ctx *ctx, int32_t symbol, const uint8_t **utf8, int32_t *len);
+
+/* Device memory helpers so that a Python host needs nothing but ctypes (no torch in the product path). */
+int  gz_device_alloc(gz_ctx *ctx, size_t bytes, void **dptr);
+int  gz_device_free(gz_ctx *ctx, void *dptr);
+int  gz_memcpy_h2d(gz_ctx *ctx, void *dst_device, const void *src_host, size_t bytes);
+int  gz_memcpy_d2h(gz_ctx *ctx, void *dst_host, const void *src_device, size_t bytes);
+
+/* With GZ_TIMING: milliseconds (HIP events on the context's stream) of the kernels of the LAST encode call:
+ * out[0] = encode kernel (scan + BPE + lookup + frame/pad/mask), out[1] = ragged finalize, out[2] = pair
+ * type-id kernel, out[3] = whole call on the stream.  Unused slots are 0. */
+int  gz_timing(gz_ctx *ctx, double out_ms[4]);
+
+/* Offline / diagnostic table build on the HOST only (no GPU needed): the same builder gz_load_tables runs, with
+ * the integer tables it would upload exposed read-only.  `which`: 0 pair hash (uint64 [slots]), 1 merges
+ * (uint32 x4 [n_lines]: left,right,merged,0), 2 symbol ids (int32 x2 [n_symbols]: non-final, final), 3 BMP code
+ * point table (uint32 x2 [65536]: plain, final), 4 astral table (uint32 x4 [slots]: cp,plain,final,0; may be
+ * empty), 5 special ids (int32 [5]).  Pointers stay valid until gz_host_tables_destroy. */
+typedef struct gz_host_tables gz_host_tables;
+int  gz_host_tables_create(const uint8_t *vocab, size_t vocab_len, const uint8_t *bpe, size_t bpe_len,
+                           const char *const specials_utf8[5], gz_host_tables **out);
+void gz_host_tables_destroy(gz_host_tables *t);
+int  gz_host_tables_array(gz_host_tables *t, int which, const void **data, int64_t *count);
+int  gz_host_tables_vocab_entry(gz_host_tables *t, int64_t i, const uint8_t **utf8, int32_t *len, int32_t *id);
+int  gz_host_tables_merge_entry(gz_host_tables *t, int64_t i, const uint8_t **utf8, int32_t *len, int32_t *n_fields, int32_t *rank);
+int  gz_host_tables_symbol(gz_host_tables *t, int32_t symbol, const uint8_t **utf8, int32_t *len);
+
+/* Multi-GPU exchange step (one process per GPU, RCCL over xGMI).  rank 0 creates an id, every rank calls
+ * gz_comm_init with it; gz_gather_rows sends each rank's [n_rows, row_len] int32 device block to `root`,
+ * which receives them back to back in rank order (grouped ncclSend/ncclRecv: each peer uses its own link). */
+int  gz_comm_unique_id(uint8_t id_out[128]);
+int  gz_comm_init(gz_ctx *ctx, const uint8_t id[128], int rank, int world);
+int  gz_gather_rows(gz_ctx *ctx, const int32_t *send_dev, int64_t n_rows_local, int32_t row_len,
+                    int32_t *recv_dev, const int64_t *rows_per_rank, int root);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GENZ_TOKENIZE_H */

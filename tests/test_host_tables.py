@@ -1,0 +1,98 @@
+"""CPU-only: the host table builder (gz_tables.cpp, through the C ABI's gz_host_tables_*) and the closed-form
+pad / pair formulas the kernels use, against the reference's golden vectors and the oracle."""
+import base64
+
+import pytest
+
+import gz_oracle as O
+from conftest import DATA, read_jsonl
+from table_sim import TableSim
+
+native = pytest.importorskip("genz_tokenize._native")
+
+
+@pytest.fixture(scope="module")
+def bundled():
+    v = open(DATA + "/vocab.txt", "rb").read()
+    b = open(DATA + "/bpe.codes", "rb").read()
+    H = native.HostTables(v, b)
+    return H, TableSim(H), O.Tables(v, b)
+
+
+def _cmp_call(sim, row):
+    if any(row.get("bytes_args", [])) or not all(isinstance(a, str) for a in row["args"]):
+        return 0
+    kw = dict(row["kwargs"])
+    if kw.pop("return_offset", False):
+        return 0
+    if "raises" in row:
+        if row["raises"] != "ValueError":
+            return 0
+        with pytest.raises(ValueError):
+            sim.call(*row["args"], **kw)
+    else:
+        got = sim.call(*row["args"], **kw)
+        want = {k: v for k, v in row["result"].items() if k != "offset"}
+        assert got == want, (row["args"], kw)
+    return 1
+
+
+def test_loader_matches_oracle_dicts(bundled):
+    H, _, t = bundled
+    assert H.vocab_items() == list(t.encoder.items())          # same insertion order, same ids
+    assert H.merge_items() == list(t.ranks.items())
+    syms = H.symbols()
+    assert len(set(syms)) == len(syms)
+    # every symbol's two vocab ids are what the encoder says about its two token spellings
+    ids = H.array(2)
+    unk = t.unk_id
+    for s, (nf, fin) in zip(syms, ids):
+        assert nf == t.encoder.get(s + "@@", unk)
+        assert fin == (t.encoder.get(s[:-4], unk) if s.endswith("</w>") else unk)
+
+
+def test_pair_hash_complete(bundled):
+    H, sim, t = bundled
+    syms = {s: i for i, s in enumerate(H.symbols())}
+    n = 0
+    for key, r in t.ranks.items():
+        if len(key) != 2:
+            continue
+        a, b = syms[key[0]], syms[key[1]]
+        assert sim.probe(a, b) == r
+        assert [int(x) for x in sim.merges[r][:3]] == [a, b, syms[key[0] + key[1]]]
+        n += 1
+    assert n == 50001      # the "#version: 0.2" header is itself a two-field line (rule L6)
+    assert sim.probe(syms["n"], syms["n"]) == t.ranks.get(("n", "n"))
+
+
+def test_g1_through_tables(bundled):
+    _, sim, _ = bundled
+    n = sum(_cmp_call(sim, r) for r in read_jsonl("g1_cases.jsonl") if r["kind"] == "call")
+    assert n >= 40
+
+
+def test_g3_through_tables(bundled):
+    _, sim, _ = bundled
+    n = sum(_cmp_call(sim, r) for r in read_jsonl("g3_random.jsonl.gz"))
+    assert n >= 2000
+
+
+def test_g4_loader_through_tables():
+    for row in read_jsonl("g4_loader.jsonl"):
+        v, b = base64.b64decode(row["vocab_b64"]), base64.b64decode(row["bpe_b64"])
+        if "calls" not in row:
+            if row["raises"] is None:
+                native.HostTables(v, b)
+            else:
+                with pytest.raises(native.GzError) as ei:
+                    native.HostTables(v, b)
+                assert ei.value.code == native.GZ_E_UTF8
+            continue
+        H = native.HostTables(v, b)
+        assert sorted(H.vocab_items(), key=lambda kv: (kv[1], kv[0])) == [tuple(x) for x in row["encoder"]], row["name"]
+        assert sorted(([list(k), r] for k, r in H.merge_items()), key=lambda kv: kv[1]) == row["bpe_ranks"], row["name"]
+        sim = TableSim(H)
+        for c in row["calls"]:
+            _cmp_call(sim, c)
+        H.close()
