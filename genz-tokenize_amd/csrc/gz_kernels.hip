@@ -25,7 +25,7 @@ constexpr int MAXSYM = 16;                   // symbols a lane-per-word merge ho
 constexpr int LONGCAP = WAVE * MAXSYM;       // symbols the wave-cooperative LDS path holds (same LDS region)
 constexpr int MAXWORDS = TILE / 2 + 1;       // a word needs >= 1 byte + >= 1 whitespace byte
 
-struct WaveLds {
+struct alignas(16) WaveLds {
     uint32_t bytes[(TILE + 16) / 4];         // tile bytes + 16 look-ahead bytes
     uint32_t sym[LONGCAP];                   // lane-per-word: sym[k*64 + lane]; long path: sym[i]
     uint16_t wstart[MAXWORDS + 3];

@@ -1,0 +1,243 @@
+"""GPU parity: the HIP path (through the C ABI and the drop-in `Tokenize`) against
+  - the golden vectors produced by the reference (G1, G3, G4),
+  - SHA-256 digests of the reference's outputs on the seeded BASELINE corpora (G5, up to the full 1 M documents),
+  - the CPU oracle on hostile / long-word / pair-mode corpora.
+Bit-exact everywhere (integer work): every comparison is ==.
+"""
+import base64
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import corpus
+import gz_oracle as O
+from conftest import DATA, GOLDEN, read_jsonl
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def tok():
+    from genz_tokenize import Tokenize
+    return Tokenize()
+
+
+@pytest.fixture(scope="module")
+def sampler():
+    return corpus.Sampler()
+
+
+def _call_matches(tok, row):
+    args = list(row["args"])
+    for i, isb in enumerate(row.get("bytes_args", [])):
+        if isb:
+            args[i] = args[i].encode()
+    kw = dict(row["kwargs"])
+    if kw.get("return_offset"):
+        return 0
+    if "raises" in row:
+        exc = {"ValueError": ValueError, "TypeError": TypeError}[row["raises"]]
+        with pytest.raises(exc) as ei:
+            tok(*args, **kw)
+        if row["raises"] == "ValueError":
+            assert str(ei.value) == row["msg"]
+    else:
+        got = tok(*args, **kw)
+        assert json.loads(json.dumps(got)) == row["result"], (args, kw)
+        assert list(got.keys()) == list(row["result"].keys())
+    return 1
+
+
+def test_g1_cases(tok):
+    n = 0
+    for row in read_jsonl("g1_cases.jsonl"):
+        k = row["kind"]
+        if k == "call":
+            n += _call_matches(tok, row)
+        elif k == "encode" and not row["return_offset"]:
+            assert tok.encode(row["text"], False) == row["result"]
+        elif k == "decode":
+            assert tok.decode(row["ids"]) == row["result"]
+        elif k == "bpe":
+            if "raises" in row:
+                with pytest.raises(IndexError):
+                    tok.bpe(row["word"])
+            else:
+                assert tok.bpe(row["word"]) == row["result"], row["word"]
+        elif k == "vocab_size":
+            assert tok.vocab_size() == row["result"]
+        elif k == "helpers":
+            assert tok.get_atttention_mask(row["ids"]) == row["attention_mask"]
+            assert tok.get_sequence_id([1, 5, 2, 2, 6, 2, 0]) == row["sequence_id"]
+    assert n >= 45
+
+
+def test_g3_random_single_calls(tok):
+    rows = read_jsonl("g3_random.jsonl.gz")
+    n = sum(_call_matches(tok, r) for r in rows)
+    assert n >= 2000
+
+
+def test_g3_random_batched(tok):
+    """The same 2 400 calls grouped by keyword arguments and run through the batch API."""
+    rows = [r for r in read_jsonl("g3_random.jsonl.gz") if not r["kwargs"].get("return_offset")]
+    groups = {}
+    for r in rows:
+        kw = r["kwargs"]
+        key = (len(r["args"]), kw.get("max_len"), kw.get("padding", True), kw.get("truncation", True))
+        groups.setdefault(key, []).append(r)
+    checked = 0
+    for (nargs, ml, pad, tr), rs in groups.items():
+        texts = [r["args"][0] for r in rs]
+        pairs = [r["args"][1] for r in rs] if nargs == 2 else None
+        out = tok.encode_batch(texts, pairs, max_len=ml, padding=pad, truncation=tr)
+        ro = out["row_off"]
+        ids = out["input_ids"].reshape(-1); mask = out["attention_mask"].reshape(-1)
+        for i, r in enumerate(rs):
+            a, b = int(ro[i]), int(ro[i + 1])
+            if "raises" in r:
+                assert out["status"][i] == 1
+                continue
+            assert out["status"][i] == 0
+            assert ids[a:b].tolist() == r["result"]["input_ids"]
+            assert mask[a:b].tolist() == r["result"]["attention_mask"]
+            if nargs == 2:
+                ns, nt = (int(x) for x in out["pair_len"][i])
+                seq = out["sequence_id"].reshape(-1)[a:a + ns].tolist()
+                tt = out["token_type_ids"].reshape(-1)[a:a + nt].tolist()
+                assert [None if v == -1 else v for v in seq] == r["result"]["sequence_id"]
+                assert [None if v == -1 else v for v in tt] == r["result"]["token_type_ids"]
+            checked += 1
+    assert checked >= 1700
+
+
+def test_g4_loader(tmp_path):
+    from genz_tokenize import Tokenize
+    for row in read_jsonl("g4_loader.jsonl"):
+        vp, bp = tmp_path / (row["name"] + ".vocab"), tmp_path / (row["name"] + ".bpe")
+        vp.write_bytes(base64.b64decode(row["vocab_b64"])); bp.write_bytes(base64.b64decode(row["bpe_b64"]))
+        if "calls" not in row:
+            if row["raises"] is None:
+                Tokenize.fromFile(str(vp), str(bp))
+            else:
+                with pytest.raises(UnicodeDecodeError):
+                    Tokenize.fromFile(str(vp), str(bp))
+            continue
+        t = Tokenize.fromFile(str(vp), str(bp))
+        assert sorted(t.encoder.items(), key=lambda kv: (kv[1], kv[0])) == [tuple(x) for x in row["encoder"]], row["name"]
+        assert sorted(t.decoder.items()) == [tuple(x) for x in row["decoder"]], row["name"]
+        assert sorted(([list(k), r] for k, r in t.bpe_ranks.items()), key=lambda kv: kv[1]) == row["bpe_ranks"]
+        assert t.vocab_size() == row["vocab_size"]
+        for c in row["calls"]:
+            _call_matches(t, c)
+
+
+def _check_hashes(tok, e, text, offs):
+    out = tok.encode_packed(text, offs, max_len=e["max_len"])
+    ids, mask = out["input_ids"], out["attention_mask"]
+    blk = e["block"]
+    for k, lo in enumerate(range(0, e["n_docs"], blk)):
+        hi = min(e["n_docs"], lo + blk)
+        assert hashlib.sha256(ids[lo:hi].tobytes()).hexdigest() == e["ids_sha256"][k], ("ids block", k)
+        assert hashlib.sha256(mask[lo:hi].tobytes()).hexdigest() == e["mask_sha256"][k], ("mask block", k)
+    assert int(mask.sum()) == e["n_tokens"]
+    assert int(out["n_real"].sum()) == e["n_tokens"]
+
+
+@pytest.mark.parametrize("name", ["cfg2_10k", "cfg3_20k", "cfg3_1M"])
+def test_g5_reference_hashes_bundled(tok, sampler, name):
+    """BASELINE configs 2 and 3 at FULL size against digests of the reference's own output."""
+    e = json.load(open(os.path.join(GOLDEN, "g5_hashes.json")))[name]
+    text, offs, L = corpus.config_corpus(e["cfg"], n_docs=e["n_docs"], sampler=sampler)
+    assert L == e["max_len"]
+    _check_hashes(tok, e, text, offs)
+
+
+def test_g5_reference_hashes_custom_tables(sampler, tmp_path):
+    """BASELINE config 5: fromFile with 100 k-entry vocab / headerless merges, 4 k-char documents, L=1024."""
+    from genz_tokenize import Tokenize
+    e = json.load(open(os.path.join(GOLDEN, "g5_hashes.json")))["cfg5_300"]
+    v, b = corpus.custom_tables()
+    (tmp_path / "v").write_bytes(v); (tmp_path / "b").write_bytes(b)
+    t = Tokenize.fromFile(str(tmp_path / "v"), str(tmp_path / "b"))
+    text, offs, L = corpus.config_corpus(5, n_docs=e["n_docs"], sampler=sampler)
+    _check_hashes(t, e, text, offs)
+
+
+def _oracle_rows(t, text, offs, pairs, ml, pad, tr):
+    raw = text.tobytes()
+    docs = [raw[offs[i]:offs[i + 1]].decode("utf-8") for i in range(len(offs) - 1)]
+    pr = None
+    if pairs is not None:
+        praw = pairs[0].tobytes()
+        pr = [praw[pairs[1][i]:pairs[1][i + 1]].decode("utf-8") for i in range(len(offs) - 1)]
+    return O.call_batch(t, docs, pr, ml, pad, tr)
+
+
+def _compare_batch(out, want, pair):
+    I, M, T, S, st = want
+    ro = out["row_off"]
+    ids = out["input_ids"].reshape(-1); mask = out["attention_mask"].reshape(-1)
+    for i in range(len(I)):
+        a, b = int(ro[i]), int(ro[i + 1])
+        assert ids[a:b].tolist() == I[i], i
+        assert mask[a:b].tolist() == M[i], i
+        assert int(out["status"][i]) == st[i], i
+        if pair and st[i] == 0:
+            ns, nt = (int(x) for x in out["pair_len"][i])
+            assert out["sequence_id"].reshape(-1)[a:a + ns].tolist() == S[i], i
+            assert out["token_type_ids"].reshape(-1)[a:a + nt].tolist() == T[i], i
+
+
+@pytest.mark.parametrize("shape", [(128, True, True), (None, True, True), (16, True, False), (7, False, True),
+                                   (1, True, True), (0, True, True), (-3, True, True)])
+def test_noisy_corpus_vs_oracle(tok, oracle_tables, sampler, shape):
+    ml, pad, tr = shape
+    text, offs, _ = corpus.config_corpus(2, n_docs=1500, seed=77, sampler=sampler)
+    text, offs = corpus.add_noise(text, offs, seed=5, rate=0.06)
+    out = tok.encode_packed(text, offs, max_len=ml, padding=pad, truncation=tr)
+    _compare_batch(out, _oracle_rows(oracle_tables, text, offs, None, ml, pad, tr), False)
+
+
+@pytest.mark.parametrize("shape", [(64, True, True), (None, True, True), (24, True, False), (5, True, True), (2, True, True)])
+def test_noisy_pairs_vs_oracle(tok, oracle_tables, sampler, shape):
+    ml, pad, tr = shape
+    ta, oa, _ = corpus.config_corpus(2, n_docs=800, seed=11, sampler=sampler)
+    tb, ob, _ = corpus.config_corpus(2, n_docs=800, seed=12, sampler=sampler)
+    ta, oa = corpus.add_noise(ta, oa, seed=1, rate=0.05)
+    tb, ob = corpus.add_noise(tb, ob, seed=2, rate=0.05)
+    out = tok.encode_packed(ta, oa, tb, ob, max_len=ml, padding=pad, truncation=tr)
+    _compare_batch(out, _oracle_rows(oracle_tables, ta, oa, (tb, ob), ml, pad, tr), True)
+
+
+def test_long_and_huge_words(tok, oracle_tables):
+    """Words of 17..1024 symbols take the wave-cooperative LDS path, longer ones the global arena pass; a word may
+    also straddle or fill whole 1-KiB tiles."""
+    import random
+    r = random.Random(9)
+    alpha = "nghiêngtrườngkhôngaaaabđ_.😀"
+    docs = []
+    for n in [17, 18, 31, 63, 64, 65, 100, 255, 256, 257, 700, 1023, 1024, 1025, 1100, 2047, 2048, 2500, 3000]:
+        w = "".join(r.choice(alpha) for _ in range(n))
+        docs.append("xin chào " + w + " việt nam\n" + w[: n // 2] + "\nhết")
+        docs.append(w)
+        docs.append(" " * (1000 - n % 7) + w + "\n")
+    docs.append("a" * 1500 + " " + "ng" * 600 + "\n" + "h" * 1024)
+    docs.append("")
+    for ml, pad, tr in [(None, True, True), (64, True, True), (4096, True, True)]:
+        out = tok.encode_batch(docs, max_len=ml, padding=pad, truncation=tr)
+        want = O.call_batch(oracle_tables, docs, None, ml, pad, tr)
+        _compare_batch(out, want, False)
+    pairs = list(reversed(docs))
+    out = tok.encode_batch(docs, pairs, max_len=None)
+    _compare_batch(out, O.call_batch(oracle_tables, docs, pairs, None, True, True), True)
+
+
+def test_deterministic(tok, sampler):
+    text, offs, L = corpus.config_corpus(3, n_docs=20000, seed=21, sampler=sampler)
+    a = tok.encode_packed(text, offs, max_len=L)
+    b = tok.encode_packed(text, offs, max_len=L)
+    assert np.array_equal(a["input_ids"], b["input_ids"]) and np.array_equal(a["attention_mask"], b["attention_mask"])
