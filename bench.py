@@ -1,0 +1,222 @@
+#!/usr/bin/env python3
+"""bench.py -- the headline measurement of BASELINE.json: UTF-8 MB/s (+ tokens/s) tokenized on N MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (Tokenize.__call__ semantics: split, BPE, vocab lookup, frame, truncate,
+pad, attention_mask) over one batch of synthetic documents that is ALREADY RESIDENT IN HBM, through the C ABI's
+device entry point; with N > 1 every rank tokenizes its own shard (weak scaling: the per-GPU batch is fixed) and
+the step ends with the RCCL gather of input_ids and attention_mask to rank 0.
+
+Workload at N=1: BASELINE.json configs[2] -- 1 M mixed-length sentences, max_len=256, bundled vocab (the
+configuration the roofline is quoted on).  With the default size the output is verified after the timed region
+against SHA-256 digests of the REFERENCE's output (tests/golden/g5_hashes.json).
+
+torch is used only for torch.distributed (rendezvous, barrier, max-over-ranks) and torch.cuda.synchronize();
+the tokenizer itself never touches it.
+"""
+import argparse
+import hashlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "genz-tokenize_amd"), os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+
+
+def cpu_baseline(text, offs, max_len, budget_s=12.0):
+    """The oracle (a from-scratch restatement of the reference's Python loop; kind "port") on a bounded prefix of
+    the same workload, one thread, one call per document -- like the reference."""
+    import gz_oracle as O
+    from corpus import VOCAB_PATH, BPE_PATH
+    t = O.Tables(open(VOCAB_PATH, "rb").read(), open(BPE_PATH, "rb").read())
+    raw = text.tobytes()
+    n = len(offs) - 1
+    t0 = time.perf_counter()
+    done = nbytes = ntok = 0
+    while done < n:
+        hi = min(n, done + 500)
+        for i in range(done, hi):
+            r = O.call(t, raw[offs[i]:offs[i + 1]].decode("utf-8"), max_len=max_len)
+            ntok += sum(r["attention_mask"])
+        nbytes += int(offs[hi] - offs[done])
+        done = hi
+        if time.perf_counter() - t0 > budget_s:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(nbytes / dt / 1e6, 4), "unit": "MB/s", "cores": 1, "kind": "port",
+            "tokens_per_s": round(ntok / dt, 1),
+            "sample": "first %d documents (%.2f MB) of the same workload, oracle/gz_oracle.py, %.1f s, "
+                      "CPython %s single thread" % (done, nbytes / 1e6, dt, sys.version.split()[0])}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--docs", type=int, default=1_000_000, help="documents per GPU")
+    ap.add_argument("--no-gather", action="store_true", help="(diagnostic) skip the RCCL gather at N > 1")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-verify", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run (one process per GPU)" % args.gpus)
+        args.gpus = world
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
+    import torch
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import corpus
+    from genz_tokenize import Tokenize, _native
+    tok = Tokenize(device=local_rank)
+    tok._sync_tables()
+    ctx = tok._ctx
+
+    # ---- workload (untimed): synthetic documents of BASELINE configs[2] (N=1) / configs[3] shards (N>1) ----------
+    seed = 3 if world == 1 else 100 + rank
+    text, offs, L = corpus.config_corpus(3, n_docs=args.docs, seed=seed)
+    n = len(offs) - 1
+    in_bytes = int(offs[-1])
+    d_text = ctx.alloc(in_bytes + 64); ctx.h2d(d_text, text)
+    d_off = ctx.alloc(8 * (n + 1)); ctx.h2d(d_off, offs)
+    d_ids = ctx.alloc(4 * n * L); d_mask = ctx.alloc(4 * n * L); d_nreal = ctx.alloc(4 * n)
+    flags = _native.GZ_PADDING | _native.GZ_TRUNCATION | _native.GZ_TIMING
+
+    gather = world > 1 and not args.no_gather
+    d_all_ids = d_all_mask = 0
+    rows_per_rank = [n] * world
+    if gather:
+        uid = [ctx.comm_unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(uid, src=0)
+        ctx.comm_init(uid[0], rank, world)
+        if rank == 0:
+            d_all_ids = ctx.alloc(4 * n * L * world); d_all_mask = ctx.alloc(4 * n * L * world)
+
+    kernel_ms = []
+
+    def step(record):
+        ctx.encode_device(d_text, d_off, 0, 0, n, L, flags, n * L, d_ids, d_mask, d_n_real=d_nreal)
+        ctx.sync()
+        if record:
+            kernel_ms.append(ctx.timing()[0])
+        if gather:
+            ctx.gather_rows(d_ids, n, L, d_all_ids, rows_per_rank, 0)
+            ctx.gather_rows(d_mask, n, L, d_all_mask, rows_per_rank, 0)
+            ctx.sync()
+
+    def fence():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- after the timed region: counts, verification, CPU baseline -------------------------------------------------
+    n_real = np.empty(n, dtype=np.int32); ctx.d2h(n_real, d_nreal)
+    tokens_local = int(n_real.sum())
+    tot = np.array([in_bytes, tokens_local, n], dtype=np.float64)
+    if dist is not None:
+        tt = torch.from_numpy(tot).cuda()
+        dist.all_reduce(tt)
+        tot = tt.cpu().numpy()
+    total_bytes, total_tokens, total_docs = float(tot[0]), float(tot[1]), int(tot[2])
+
+    verify = None
+    if rank == 0 and not args.no_verify:
+        ids = np.empty((n, L), dtype=np.int32); ctx.d2h(ids, d_ids)
+        mask = np.empty((n, L), dtype=np.int32); ctx.d2h(mask, d_mask)
+        g5 = json.load(open(os.path.join(ROOT, "tests", "golden", "g5_hashes.json"))).get("cfg3_1M")
+        if world == 1 and g5 and n == g5["n_docs"] and L == g5["max_len"]:
+            blk = g5["block"]
+            ok = all(hashlib.sha256(ids[lo:lo + blk].tobytes()).hexdigest() == g5["ids_sha256"][k] and
+                     hashlib.sha256(mask[lo:lo + blk].tobytes()).hexdigest() == g5["mask_sha256"][k]
+                     for k, lo in enumerate(range(0, n, blk)))
+            verify = "reference sha256 (tests/golden/g5_hashes.json cfg3_1M): %s" % ("match" if ok else "MISMATCH")
+            if not ok:
+                sys.exit("bench: output differs from the reference digests")
+        else:
+            import gz_oracle as O
+            t = O.Tables(open(corpus.VOCAB_PATH, "rb").read(), open(corpus.BPE_PATH, "rb").read())
+            raw = text.tobytes()
+            for i in range(0, n, max(1, n // 200)):
+                w = O.call(t, raw[offs[i]:offs[i + 1]].decode(), max_len=L)
+                if ids[i].tolist() != w["input_ids"] or mask[i].tolist() != w["attention_mask"]:
+                    sys.exit("bench: document %d differs from the oracle" % i)
+            verify = "oracle on a 200-document stride sample: match"
+        if gather:
+            allids = np.empty((n * world, L), dtype=np.int32); ctx.d2h(allids, d_all_ids)
+            if not np.array_equal(allids[:n], ids):
+                sys.exit("bench: gathered block of rank 0 differs from its local rows")
+            verify += "; gathered [%d, %d] block checked for rank 0" % (n * world, L)
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        k_ms = float(np.mean(kernel_ms))
+        algo = in_bytes + 8 * (n + 1) + 4 * n * L * 2 + 4 * n           # bytes per launch (one rank)
+        achieved = algo / (k_ms * 1e-3) / 1e9
+        out = {
+            "metric": "UTF-8 MB/s tokenized (Tokenize.__call__ hot path: split + BPE + vocab lookup + pad/trunc + mask)",
+            "value": round(total_bytes * args.steps / elapsed / 1e6, 2),
+            "unit": "MB/s",
+            "tokens_per_s": round(total_tokens * args.steps / elapsed, 1),
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8 in / int32 out (integer + byte indexing, no floating point)",
+            "data": "synthetic (unigram sampler over the bundled vocab.txt counts, corpus.py; seed %s)" % (
+                "3" if world == 1 else "100+rank"),
+            "config": {"workload": "BASELINE configs[2]: %d mixed-length sentences per GPU (70%% 5-30 / 25%% 31-120 / "
+                                   "5%% 121-400 words), max_len=%d pad+trunc, bundled vocab" % (n, L),
+                       "docs_total": total_docs, "input_bytes_total": int(total_bytes),
+                       "tokens_total": int(total_tokens),
+                       "sharding": "dp%d by documents, RCCL gatherv of ids+mask to rank 0%s" % (
+                           world, "" if gather or world == 1 else " DISABLED (--no-gather)") if world > 1 else "single GPU",
+                       "inputs": "resident in HBM before the timed region"},
+            "roofline": {"bound": "hbm", "kernel": "gz_encode_kernel", "achieved": round(achieved, 2),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
+                         "traffic": None, "algorithmic_bytes_per_launch": algo,
+                         "kernel_ms_avg": round(k_ms, 4), "timed_with": "hipEvents on the library's stream"},
+            "verified": verify,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(text, offs, L)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

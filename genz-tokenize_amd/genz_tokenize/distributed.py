@@ -1,0 +1,82 @@
+"""Multi-GPU model of the hot path: one process per GPU, documents sharded, rows gathered to a root.
+
+The reference has no parallelism of any kind; documents are independent (no word cache, no
+cross-document state), so the batch shards by contiguous document ranges and the only exchange step is the
+gather of the `[n_r, max_len]` int32 blocks (input_ids, attention_mask) to the root rank, done by the C ABI's
+`gz_gather_rows` (grouped ncclSend/ncclRecv over xGMI: every peer uses its own link to the root).
+
+The planning and bookkeeping live here so that they can be exercised on CPU with `gloo` (tests/test_distributed.py)
+through the `Transport` interface; on GPUs the transport is RCCL inside the C library.
+"""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+import numpy as np
+
+
+def plan_shards(offsets: np.ndarray, world: int) -> List[Tuple[int, int]]:
+    """Contiguous document ranges [lo, hi) per rank, balanced by BYTES: rank r's range ends at the document
+    boundary nearest to total_bytes*(r+1)/world.  Ranges concatenate to the input order."""
+    n = len(offsets) - 1
+    base, total = int(offsets[0]), int(offsets[-1] - offsets[0])
+    cuts = [0]
+    for r in range(1, world):
+        target = base + total * r / world
+        k = int(np.searchsorted(offsets, target, side="left"))
+        if k > 0 and k <= n and abs(int(offsets[k - 1]) - target) <= abs(int(offsets[min(k, n)]) - target):
+            k -= 1
+        cuts.append(min(max(k, cuts[-1]), n))
+    cuts.append(n)
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+class Transport:
+    """gatherv of int32 row blocks to a root."""
+
+    rank: int
+    world: int
+
+    def gather_rows(self, local, rows_per_rank: Sequence[int], row_len: int, root: int = 0):
+        raise NotImplementedError
+
+
+class RcclTransport(Transport):
+    """Device-resident gather through gz_gather_rows.  `local` and the returned handle are device pointers."""
+
+    def __init__(self, ctx, rank: int, world: int, uid: bytes):
+        self.ctx, self.rank, self.world = ctx, rank, world
+        ctx.comm_init(uid, rank, world)
+
+    def gather_rows(self, d_local: int, rows_per_rank, row_len, root=0, d_recv: int = 0):
+        self.ctx.gather_rows(d_local, int(rows_per_rank[self.rank]), row_len, d_recv, rows_per_rank, root)
+        return d_recv
+
+
+class GlooTransport(Transport):
+    """Same contract over torch.distributed point-to-point on CPU tensors (tests only)."""
+
+    def __init__(self, rank: int, world: int):
+        self.rank, self.world = rank, world
+
+    def gather_rows(self, local: np.ndarray, rows_per_rank, row_len, root=0):
+        import torch
+        import torch.distributed as dist
+        local = np.ascontiguousarray(local, dtype=np.int32).reshape(-1, row_len)
+        assert local.shape[0] == rows_per_rank[self.rank]
+        if self.rank != root:
+            if local.size:
+                dist.send(torch.from_numpy(local), dst=root)
+            return None
+        out = np.empty((int(sum(rows_per_rank)), row_len), dtype=np.int32)
+        row0 = 0
+        for q in range(self.world):
+            k = int(rows_per_rank[q])
+            if q == root:
+                out[row0:row0 + k] = local
+            elif k:
+                buf = torch.empty((k, row_len), dtype=torch.int32)
+                dist.recv(buf, src=q)
+                out[row0:row0 + k] = buf.numpy()
+            row0 += k
+        return out
