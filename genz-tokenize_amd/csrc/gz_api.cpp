@@ -88,6 +88,9 @@ struct gz_ctx {
 
     void* comm = nullptr;
     int rank = 0, world = 1;
+
+    const int64_t* hint_off = nullptr;   // last device offsets array whose byte total was read back
+    int64_t hint_n = -1, hint_bytes = 0;
 };
 
 namespace {
@@ -204,7 +207,8 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
                          const int64_t* pair_off, int64_t n_docs, int32_t max_len, uint32_t flags, int64_t capacity,
                          int32_t* input_ids, int32_t* attention_mask, int32_t* token_type_ids, int32_t* sequence_id,
                          int64_t* row_off, int32_t* pair_len, int32_t* n_real, int32_t* status,
-                         int64_t raw_elems /* < 0: unknown, read offsets from the device */)
+                         int64_t raw_elems /* < 0: unknown, read offsets from the device */,
+                         int64_t text_bytes /* < 0: unknown */)
 {
     if (!c->have_tables) return fail(c, GZ_E_NOTABLES, "gz_load_tables has not been called");
     if (n_docs < 0 || !text_off || (n_docs > 0 && !text)) return fail(c, GZ_E_INVALID, "bad text arguments");
@@ -230,6 +234,26 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
     A.n_docs = n_docs; A.dense = dense ? 1 : 0; A.max_len = max_len;
     A.ids = input_ids; A.mask = attention_mask; A.raw = nullptr; A.n_real = n_real;
     A.defer_flag = (int32_t*)c->w_flags.p; A.arena = nullptr; A.huge_pass = 0;
+    // documents per wave: enough bytes per wave to fill its 1-KiB tiles, enough waves to fill the chip
+    if (text_bytes < 0) {
+        if (c->hint_off == text_off && c->hint_n == n_docs) text_bytes = c->hint_bytes;   // speed only: a stale hint is harmless
+        else {
+            int64_t b[2] = {0, 0};
+            HIPCHK(c, hipMemcpy(&b[0], text_off, 8, hipMemcpyDeviceToHost));
+            HIPCHK(c, hipMemcpy(&b[1], text_off + n_docs, 8, hipMemcpyDeviceToHost));
+            text_bytes = b[1] - b[0];
+            c->hint_off = text_off; c->hint_n = n_docs; c->hint_bytes = text_bytes;
+        }
+    }
+    {
+        const int64_t avg = n_docs > 0 ? text_bytes / n_docs : 0;
+        int64_t dpw = avg > 0 ? 2048 / avg : GZ_MAX_DOCS_PER_WAVE;
+        const int64_t by_waves = n_docs / 16384;                 // keep >= 16 K waves when the batch allows it
+        if (dpw > by_waves) dpw = by_waves;
+        if (dpw < 1) dpw = 1;
+        if (dpw > GZ_MAX_DOCS_PER_WAVE) dpw = GZ_MAX_DOCS_PER_WAVE;
+        A.docs_per_wave = (int32_t)dpw;
+    }
     if (!dense) {
         if (raw_elems < 0) {
             int64_t b[4] = {0, 0, 0, 0};
@@ -408,7 +432,7 @@ int gz_encode_batch_device(gz_ctx* c, const uint8_t* text, const int64_t* text_o
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     return encode_device_locked(c, text, text_off, pair, pair_off, n_docs, max_len, flags, capacity, input_ids,
-                                attention_mask, token_type_ids, sequence_id, row_off, pair_len, n_real, status, -1);
+                                attention_mask, token_type_ids, sequence_id, row_off, pair_len, n_real, status, -1, -1);
 }
 
 int gz_sync(gz_ctx* c)
@@ -482,7 +506,7 @@ int gz_encode_batch(gz_ctx* c, const uint8_t* text, const int64_t* text_off, con
                               n_docs, max_len, flags, out_elems, (int32_t*)c->w_ids.p, (int32_t*)c->w_mask.p,
                               is_pair ? (int32_t*)c->w_tt.p : nullptr, is_pair ? (int32_t*)c->w_seq.p : nullptr,
                               (int64_t*)c->w_rowoff.p, is_pair ? (int32_t*)c->w_pairlen.p : nullptr,
-                              (int32_t*)c->w_nreal.p, is_pair ? (int32_t*)st2.p : nullptr, raw_elems);
+                              (int32_t*)c->w_nreal.p, is_pair ? (int32_t*)st2.p : nullptr, raw_elems, tb);
     if (rc == GZ_OK) rc = sync_locked(c);
     if (rc) { release(st2); return rc; }
 

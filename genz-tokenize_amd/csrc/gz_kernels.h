@@ -3,7 +3,8 @@
 #include "gz_common.h"
 #include <hip/hip_runtime.h>
 
-constexpr int GZ_WAVES_PER_BLOCK = 4;
+constexpr int GZ_WAVES_PER_BLOCK = 2;
+constexpr int GZ_MAX_DOCS_PER_WAVE = 16;  // a wave owns up to this many consecutive documents
 constexpr int32_t GZ_DEFERRED = -1;     // n_real value of a document waiting for the arena pass
 constexpr int32_t GZ_NONE_ = -1;        // == GZ_NONE of the public header
 
@@ -26,7 +27,8 @@ struct GzEncodeArgs {
     int32_t* n_real;      // [n_docs] dense: min(T, max_len); ragged: T (raw token count); GZ_DEFERRED
     int32_t* defer_flag;  // set to 1 when some document needs the arena
     uint32_t* arena;      // nullptr, or 4 bytes per input byte (text then pair)
-    int32_t huge_pass;    // 1: only documents whose n_real == GZ_DEFERRED
+    int32_t huge_pass;    // 1: only groups whose first document has n_real == GZ_DEFERRED
+    int32_t docs_per_wave; // 1 .. GZ_MAX_DOCS_PER_WAVE (chosen by the host from the average document size)
 };
 
 struct GzFinalizeArgs {

@@ -19,17 +19,30 @@
 namespace {
 
 constexpr int WAVE = 64;
-constexpr int WPB = GZ_WAVES_PER_BLOCK;      // waves (documents) per workgroup
+constexpr int WPB = GZ_WAVES_PER_BLOCK;      // waves per workgroup (each wave owns a group of documents)
 constexpr int TILE = 1024;                   // bytes classified per tile: 16 per lane
 constexpr int MAXSYM = 16;                   // symbols a lane-per-word merge holds
 constexpr int LONGCAP = WAVE * MAXSYM;       // symbols the wave-cooperative LDS path holds (same LDS region)
 constexpr int MAXWORDS = TILE / 2 + 1;       // a word needs >= 1 byte + >= 1 whitespace byte
+constexpr int GMAX = GZ_MAX_DOCS_PER_WAVE;   // documents per wave
+constexpr int RECCAP = 1024;                 // word records buffered between two flushes
+constexpr int MISSCAP = WAVE;                // words waiting for the merge loop (one lane each)
+constexpr uint32_t REC_MISS = 0x80000000u;   // record = [miss:1][doc:5][payload:26]  payload = vocab id | miss slot
 
 struct alignas(16) WaveLds {
     uint32_t bytes[(TILE + 16) / 4];         // tile bytes + 16 look-ahead bytes
     uint32_t sym[LONGCAP];                   // lane-per-word: sym[k*64 + lane]; long path: sym[i]
+    uint32_t rec[RECCAP];
+    uint32_t miss_off[MISSCAP];              // word start, relative to the first byte of the wave's range
+    uint32_t brk[TILE / 32];                 // document boundaries inside the current tile
+    uint32_t doc_rel[GMAX + 1];              // document starts, relative to the first byte of the wave's range
+    int32_t  doc_ntok[GMAX];                 // raw tokens emitted so far per document
+    int64_t  row_base[GMAX];                 // element offset of each document's row
     uint16_t wstart[MAXWORDS + 3];
     uint16_t wend[MAXWORDS + 3];
+    uint16_t miss_len[MISSCAP];              // bytes | glue << 15
+    uint8_t  miss_ntok[MISSCAP];
+    uint8_t  pad_hit[GMAX];                  // a real token of this document equals the pad id (mask needs the slow path)
 };
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
@@ -130,6 +143,7 @@ struct Emit {
     int stop;            // stop tokenizing once ntok >= stop (dense: max_len)
     int ntok;            // wave-uniform count of raw tokens so far
     int32_t pad_id;
+    uint8_t* pad_hit;    // set to 1 when an emitted id equals the pad id (nullptr: not tracked)
 };
 
 __device__ __forceinline__ void emit_at(const Emit& E, int pos, int32_t id)
@@ -137,6 +151,7 @@ __device__ __forceinline__ void emit_at(const Emit& E, int pos, int32_t id)
     if (pos < E.limit) {
         E.ids[pos] = id;
         if (E.mask) E.mask[pos] = id != E.pad_id ? 1 : 0;
+        if (E.pad_hit && id == E.pad_id) *E.pad_hit = 1;
     }
 }
 
@@ -240,8 +255,9 @@ __device__ bool long_word(const GzDeviceTables& T, WaveLds& L, const uint8_t* g,
 //   end   bit j : a word ends before byte 16*lane+j (whitespace lead byte whose previous byte is not whitespace)
 // `prev_ws0`: the byte before the tile counts as whitespace (tile begins at a word boundary); then leading
 // continuation bytes (tail of a whitespace code point cut by the previous tile) count as whitespace too.
+// `brk16`: bit j set = a document starts at byte 16*lane+j.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void classify(const uint32_t w[4], uint32_t w4, int lane, bool prev_ws0,
+__device__ __forceinline__ void classify(const uint32_t w[4], uint32_t w4, int lane, bool prev_ws0, uint32_t brk16,
                                          uint32_t& start16, uint32_t& end16)
 {
     uint32_t lead = 0, ws = 0, ws23 = 0, ws3 = 0;
@@ -273,8 +289,9 @@ __device__ __forceinline__ void classify(const uint32_t w[4], uint32_t w4, int l
     }
     full = (full | carry) & 0xFFFFu;
     const uint32_t prev_ws = ((full << 1) | prevbit) & 0xFFFFu;
-    start16 = lead & ~ws & prev_ws & 0xFFFFu;
-    end16 = ws & ~prev_ws & 0xFFFFu;
+    // a document boundary (brk16) ends the word before it and lets a word start at it
+    start16 = lead & ~ws & (prev_ws | brk16) & 0xFFFFu;
+    end16 = (ws | brk16) & ~prev_ws & 0xFFFFu;
 }
 
 // Load the tile [pos, pos+TILE+16) of a document that ends at `end` into registers (bytes past the end read as
@@ -322,133 +339,273 @@ __device__ __forceinline__ void load_tile(const uint8_t* base, int64_t pos, int6
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// One text (text A or text B of a document): __tokenize + ids (tokenize.py:103-133).
-// Returns false if the document must be deferred to the arena pass.
+// A wave owns a GROUP of consecutive documents and streams the bytes of the group (text A of every document,
+// then text B) tile by tile.  Words of all documents of a tile share the 64 lanes; per word a RECORD is buffered
+// (vocab id when the whole-word table answers, otherwise a slot in the miss list), misses are merged 64 at a
+// time (one lane per word, tokenize.py:62-101), and a flush turns records into row positions with a segmented
+// prefix sum per document (bos/eos framing and truncation: tokenize.py:126-146).
 // ---------------------------------------------------------------------------------------------------------------
-__device__ bool encode_text(const GzDeviceTables& T, WaveLds& L, const uint8_t* base, int64_t b0, int64_t b1,
-                            int64_t buf_end, uint32_t* arena, Emit& E, int lane)
+struct Group {
+    const GzDeviceTables& T;
+    WaveLds& L;
+    int lane;
+    int g;                    // documents in this group
+    int32_t* out;             // dense: input_ids; ragged: raw rows
+    int limit, stop;          // positions >= limit are dropped; a document with >= stop tokens needs no more work
+    const uint8_t* base;      // text A or text B (absolute offsets index it)
+    int64_t B0, B1, buf_end;  // byte range of the group in `base`, end of the whole buffer
+    uint32_t* arena;          // nullptr or global scratch indexed like `base`
+    int nrec, nmiss;          // buffered records / misses (wave-uniform)
+};
+
+__device__ __forceinline__ void group_emit(Group& G, int doc, int pos, int32_t id)
 {
+    if (pos < G.limit) {
+        G.out[G.L.row_base[doc] + pos] = id;
+        if (id == G.T.pad_id) G.L.pad_hit[doc] = 1;
+    }
+}
+
+// document (index inside the group) that owns relative byte offset a
+__device__ __forceinline__ int doc_of(const Group& G, uint32_t a)
+{
+    int j = 0;
+#pragma unroll
+    for (int step = GMAX / 2; step >= 1; step >>= 1) {
+        const int k = j + step;
+        if (k < G.g && G.L.doc_rel[k] <= a) j = k;
+    }
+    return j;
+}
+
+// merge loop of one lane's word held in L.sym[k*64+lane], k < n   (tokenize.py:69-98)
+__device__ __forceinline__ int lane_merge(const GzDeviceTables& T, WaveLds& L, int lane, int n)
+{
+    while (n > 1) {
+        uint32_t best = GZ_RANK_NONE;
+        uint32_t a = L.sym[lane];
+        for (int k = 1; k < n; ++k) {
+            const uint32_t b = L.sym[k * WAVE + lane];
+            const uint32_t r = probe_rank(T, a, b);
+            best = r < best ? r : best;
+            a = b;
+        }
+        if (best == GZ_RANK_NONE) break;
+        const GzMergeInfo mi = T.merges[best];
+        int j = 0, k = 0;
+        while (k < n) {
+            const uint32_t s = L.sym[k * WAVE + lane];
+            if (k + 1 < n && s == mi.left && L.sym[(k + 1) * WAVE + lane] == mi.right) {
+                L.sym[j * WAVE + lane] = mi.merged;
+                k += 2;
+            } else {
+                L.sym[j * WAVE + lane] = s;
+                k += 1;
+            }
+            ++j;
+        }
+        n = j;
+    }
+    return n;
+}
+
+// Turn the buffered records into tokens in their rows.
+__device__ void group_flush(Group& G)
+{
+    WaveLds& L = G.L;
+    const GzDeviceTables& T = G.T;
+    const int lane = G.lane;
+    if (G.nrec == 0) return;
+    // ---- the misses: decode, merge, look up (one lane per word) ---------------------------------------------------
+    if (G.nmiss > 0) {
+        if (lane < G.nmiss) {
+            const uint8_t* g = G.base + G.B0 + L.miss_off[lane];
+            const int nb = L.miss_len[lane] & 0x7FFF;
+            const bool glue = (L.miss_len[lane] >> 15) != 0;
+            auto at = [&](int64_t i) -> uint32_t { return g[i]; };
+            int n = 0, i = 0;
+            while (i < nb) {
+                int len;
+                const uint32_t cp = decode_cp(at, i, nb, len);
+                L.sym[n * WAVE + lane] = initial_symbol(T, cp, !glue && i + len >= nb);
+                ++n;
+                i += len;
+            }
+            if (glue) { L.sym[n * WAVE + lane] = initial_symbol(T, 0x0Au, true); ++n; }
+            n = lane_merge(T, L, lane, n);
+            for (int k = 0; k < n; ++k) L.sym[k * WAVE + lane] = (uint32_t)token_id(T, L.sym[k * WAVE + lane], k == n - 1);
+            L.miss_ntok[lane] = (uint8_t)n;
+        }
+    }
+    // ---- positions: segmented exclusive prefix sum of the token counts, one segment per document -----------------
+    for (int c0 = 0; c0 < G.nrec; c0 += WAVE) {
+        const int r = c0 + lane;
+        const bool valid = r < G.nrec;
+        const uint32_t rec = valid ? L.rec[r] : 0u;
+        const int doc = (int)((rec >> 26) & 31u);
+        const bool miss = (rec & REC_MISS) != 0;
+        const uint32_t payload = rec & 0x03FFFFFFu;
+        const int cnt = valid ? (miss ? (int)L.miss_ntok[payload] : 1) : 0;
+        int total;
+        const int excl = wave_excl_sum(cnt, lane, total);
+        const int prevdoc = __shfl_up(doc, 1, WAVE);
+        const uint64_t heads = __ballot(valid && (lane == 0 || prevdoc != doc));
+        const uint64_t below = heads & (lane == 63 ? ~0ull : ((2ull << lane) - 1ull));
+        const int f = below ? 63 - __clzll((long long)below) : 0;
+        const int seg_excl = excl - __shfl(excl, f, WAVE);
+        const int nextdoc = __shfl_down(doc, 1, WAVE);
+        const bool tail = valid && (lane == 63 || r + 1 >= G.nrec || nextdoc != doc);
+        if (valid) {
+            const int pos = L.doc_ntok[doc] + seg_excl;
+            if (!miss) group_emit(G, doc, pos, (int32_t)payload);
+            else for (int k = 0; k < cnt; ++k) group_emit(G, doc, pos + k, (int32_t)L.sym[k * WAVE + payload]);
+            if (tail) L.doc_ntok[doc] = pos + cnt;
+        }
+    }
+    G.nrec = 0;
+    G.nmiss = 0;
+}
+
+// a word that does not fit a lane: flush what precedes it, then merge it wave-cooperatively and emit directly
+__device__ bool group_long_word(Group& G, int64_t gpos, int64_t nbytes, bool glue)
+{
+    group_flush(G);
+    const int doc = doc_of(G, (uint32_t)(gpos - G.B0));
+    Emit E;
+    E.ids = G.out + G.L.row_base[doc];
+    E.mask = nullptr; E.symout = nullptr;
+    E.limit = G.limit; E.stop = G.stop; E.pad_id = G.T.pad_id;
+    E.pad_hit = &G.L.pad_hit[doc];
+    E.ntok = G.L.doc_ntok[doc];
+    if (E.ntok < G.stop) {
+        if (!long_word(G.T, G.L, G.base + gpos, nbytes, glue, G.arena ? G.arena + gpos : nullptr, E, G.lane)) return false;
+        if (G.lane == 0) G.L.doc_ntok[doc] = E.ntok;
+    }
+    return true;
+}
+
+// load + classify the tile at `pos` (document boundaries included); word starts / ends as per-lane 16-bit masks
+__device__ __forceinline__ void group_tile(Group& G, int64_t pos, bool prev_ws0, uint32_t& st16, uint32_t& en16)
+{
+    WaveLds& L = G.L;
+    const int lane = G.lane;
+    uint32_t w[4], w4;
+    load_tile(G.base, pos, G.B1, G.buf_end, lane, w, w4, L);
+    if (lane < TILE / 32) L.brk[lane] = 0;
+    if (lane >= 1 && lane < G.g) {
+        const int64_t r = (int64_t)L.doc_rel[lane] - (pos - G.B0);
+        if (r > 0 && r < TILE) atomicOr(&L.brk[r >> 5], 1u << (r & 31));
+    }
+    const uint32_t brk16 = (L.brk[lane >> 1] >> ((lane & 1) * 16)) & 0xFFFFu;
+    classify(w, w4, lane, prev_ws0, brk16, st16, en16);
+}
+
+// One text (A or B) of every document of the group: __tokenize + ids (tokenize.py:103-133).
+// Returns false if the group must be deferred to the arena pass.
+__device__ bool group_text(Group& G)
+{
+    WaveLds& L = G.L;
+    const GzDeviceTables& T = G.T;
+    const int lane = G.lane;
     const uint8_t* lds_bytes = reinterpret_cast<const uint8_t*>(L.bytes);
-    int64_t pos = b0;
-    while (pos < b1 && E.ntok < E.stop) {
-        uint32_t w[4], w4;
-        load_tile(base, pos, b1, buf_end, lane, w, w4, L);
+    int64_t pos = G.B0;
+    while (pos < G.B1) {
         uint32_t st16, en16;
-        classify(w, w4, lane, true, st16, en16);
+        group_tile(G, pos, true, st16, en16);
         int n_starts, n_ends;
         int sidx = wave_excl_sum(__popc(st16), lane, n_starts);
         int eidx = wave_excl_sum(__popc(en16), lane, n_ends);
         for (uint32_t m = st16; m; m &= m - 1) L.wstart[sidx++] = (uint16_t)(16 * lane + __ffs(m) - 1);
         for (uint32_t m = en16; m; m &= m - 1) L.wend[eidx++] = (uint16_t)(16 * lane + __ffs(m) - 1);
-        // (LDS traffic of one wave is ordered; no barrier is needed between its own writes and reads)
+        const uint32_t tile_rel = (uint32_t)(pos - G.B0);
 
         const int nw = n_ends;                                  // complete words of this tile
-        for (int wbase = 0; wbase < nw && E.ntok < E.stop; wbase += WAVE) {
+        for (int wbase = 0; wbase < nw; wbase += WAVE) {
             const int wi = wbase + lane;
-            const bool have = wi < nw;
+            bool have = wi < nw;
             const int ws = have ? L.wstart[wi] : 0;
             const int we = have ? L.wend[wi] : 0;
-            const bool glue = have && lds_bytes[we] == 0x0Au;   // "\S+\n?"
-            int seg_lo = 0;
+            const bool glue = have && lds_bytes[we] == 0x0Au && !((L.brk[we >> 5] >> (we & 31)) & 1u);   // "\S+\n?"
+            const int nb = we - ws;
+            const uint32_t a_rel = tile_rel + (uint32_t)ws;
+            const int doc = have ? doc_of(G, a_rel) : 0;
+            if (have && L.doc_ntok[doc] >= G.stop) have = false;       // row already full: the word cannot matter
+            bool is_long = false;
+            if (have && nb + (glue ? 1 : 0) > MAXSYM) {
+                int leads = glue ? 1 : 0;
+                for (int i = ws; i < we; ++i) leads += (lds_bytes[i] & 0xC0u) != 0x80u;
+                is_long = leads > MAXSYM;
+            }
+            const bool hit = false;
+            const uint32_t hit_id = 0;
+            // append in word order; a lane that does not fit (or is long) cuts the round: flush, then go on
+            int lo = 0;
             for (;;) {
-                const bool act = have && lane >= seg_lo;
-                int n = 0;
-                bool is_long = false;
-                if (act) {
-                    auto at = [&](int64_t i) -> uint32_t { return lds_bytes[i]; };
-                    int i = ws;
-                    while (i < we) {
-                        int len;
-                        const uint32_t cp = decode_cp(at, i, we, len);
-                        if (n == MAXSYM) { is_long = true; break; }
-                        L.sym[n * WAVE + lane] = initial_symbol(T, cp, !glue && i + len >= we);
-                        ++n;
-                        i += len;
+                const bool rem = have && lane >= lo;
+                const bool missr = rem && !hit && !is_long;
+                const uint64_t remb = __ballot(rem), missb = __ballot(missr);
+                const int rp = __popcll(remb & lt_mask(lane)), mp = __popcll(missb & lt_mask(lane));
+                const bool fits = rem && !is_long && (G.nmiss + mp + (missr ? 1 : 0) <= MISSCAP) && (G.nrec + rp < RECCAP);
+                const uint64_t nofit = __ballot(rem && !fits);
+                const int cut = nofit ? __ffsll((unsigned long long)nofit) - 1 : WAVE;
+                const bool app = rem && lane < cut;
+                if (app) {
+                    uint32_t rec = (uint32_t)doc << 26;
+                    if (missr) {
+                        const int m = G.nmiss + mp;
+                        L.miss_off[m] = a_rel;
+                        L.miss_len[m] = (uint16_t)(nb | (glue ? 0x8000 : 0));
+                        rec |= REC_MISS | (uint32_t)m;
+                    } else {
+                        rec |= hit_id;
                     }
-                    if (glue && !is_long) {
-                        if (n == MAXSYM) is_long = true;
-                        else { L.sym[n * WAVE + lane] = initial_symbol(T, 0x0Au, true); ++n; }
-                    }
+                    L.rec[G.nrec + rp] = rec;
                 }
-                const uint64_t lm = __ballot(act && is_long);
-                const int f = lm ? __ffsll((unsigned long long)lm) - 1 : WAVE;
-                const bool run = act && lane < f;
-                if (run) {
-                    // the merge loop, one lane per word (tokenize.py:69-98)
-                    while (n > 1) {
-                        uint32_t best = GZ_RANK_NONE;
-                        uint32_t a = L.sym[lane];
-                        for (int k = 1; k < n; ++k) {
-                            const uint32_t b = L.sym[k * WAVE + lane];
-                            const uint32_t r = probe_rank(T, a, b);
-                            best = r < best ? r : best;
-                            a = b;
-                        }
-                        if (best == GZ_RANK_NONE) break;
-                        const GzMergeInfo mi = T.merges[best];
-                        int j = 0, k = 0;
-                        while (k < n) {
-                            const uint32_t s = L.sym[k * WAVE + lane];
-                            if (k + 1 < n && s == mi.left && L.sym[(k + 1) * WAVE + lane] == mi.right) {
-                                L.sym[j * WAVE + lane] = mi.merged;
-                                k += 2;
-                            } else {
-                                L.sym[j * WAVE + lane] = s;
-                                k += 1;
-                            }
-                            ++j;
-                        }
-                        n = j;
-                    }
+                G.nrec += __popcll(__ballot(app));
+                G.nmiss += __popcll(__ballot(app && missr));
+                if (cut == WAVE) break;
+                if (__shfl((int)is_long, cut, WAVE)) {
+                    const int fs = __shfl(ws, cut, WAVE), fe = __shfl(we, cut, WAVE);
+                    const bool fg = __shfl((int)glue, cut, WAVE) != 0;
+                    if (!group_long_word(G, pos + fs, fe - fs, fg)) return false;
+                    lo = cut + 1;
+                } else {
+                    group_flush(G);
+                    lo = cut;
                 }
-                int total;
-                const int off = wave_excl_sum(run ? n : 0, lane, total);
-                if (run) {
-                    for (int k = 0; k < n; ++k) {
-                        const uint32_t s = L.sym[k * WAVE + lane];
-                        if (E.symout) { if (E.ntok + off + k < E.limit) E.symout[E.ntok + off + k] = (int32_t)s; }
-                        else emit_at(E, E.ntok + off + k, token_id(T, s, k == n - 1));
-                    }
-                }
-                E.ntok += total;
-                if (f == WAVE || E.ntok >= E.stop) break;
-                // word of lane f is too long for one lane
-                const int fs = __shfl(ws, f, WAVE), fe = __shfl(we, f, WAVE);
-                const bool fg = __shfl((int)glue, f, WAVE) != 0;
-                const int64_t gpos = pos + fs;
-                if (!long_word(T, L, base + gpos, fe - fs, fg, arena ? arena + gpos : nullptr, E, lane)) return false;
-                seg_lo = f + 1;
             }
         }
-        if (E.ntok >= E.stop) break;
 
         if (n_starts > n_ends) {
             const int s_last = L.wstart[n_ends];
             if (s_last > 0) { pos += s_last; continue; }        // re-tile at the start of the cut word
             // a word that fills the whole tile: find its end by scanning forward
             int64_t q = pos + TILE;
-            int64_t wend_abs = b1;
-            while (q < b1) {
-                uint32_t ww[4], ww4, s2, e2;
-                load_tile(base, q, b1, buf_end, lane, ww, ww4, L);
-                classify(ww, ww4, lane, false, s2, e2);
+            int64_t wend_abs = G.B1;
+            bool at_break = false;
+            while (q < G.B1) {
+                uint32_t s2, e2;
+                group_tile(G, q, false, s2, e2);
                 const uint64_t any = __ballot(e2 != 0);
                 if (any) {
                     const int fl = __ffsll((unsigned long long)any) - 1;
                     const uint32_t eb = (uint32_t)__shfl((int)e2, fl, WAVE);
-                    wend_abs = q + 16 * fl + __ffs(eb) - 1;
+                    const int p = 16 * fl + __ffs(eb) - 1;
+                    wend_abs = q + p;
+                    at_break = ((L.brk[p >> 5] >> (p & 31)) & 1u) != 0;
                     break;
                 }
                 q += TILE;
             }
-            if (wend_abs > b1) wend_abs = b1;
-            const bool fg = wend_abs < b1 && base[wend_abs] == 0x0A;
-            if (!long_word(T, L, base + pos, wend_abs - pos, fg, arena ? arena + pos : nullptr, E, lane)) return false;
+            if (wend_abs > G.B1) wend_abs = G.B1;
+            const bool fg = wend_abs < G.B1 && !at_break && G.base[wend_abs] == 0x0A;
+            if (!group_long_word(G, pos, wend_abs - pos, fg)) return false;
             pos = wend_abs + (fg ? 1 : 0);
         } else {
             pos += TILE;
         }
     }
+    group_flush(G);
     return true;
 }
 
@@ -462,64 +619,100 @@ __global__ __launch_bounds__(WAVE * WPB) void gz_encode_kernel(GzDeviceTables T,
     __shared__ WaveLds lds[WPB];
     const int lane = lane_id();
     const int wv = threadIdx.x / WAVE;
-    const int64_t d = (int64_t)blockIdx.x * WPB + wv;
-    if (d >= A.n_docs) return;
-    if (A.huge_pass && A.n_real[d] != GZ_DEFERRED) return;
+    const int64_t d0 = ((int64_t)blockIdx.x * WPB + wv) * A.docs_per_wave;
+    if (d0 >= A.n_docs) return;
+    if (A.huge_pass && A.n_real[d0] != GZ_DEFERRED) return;
     WaveLds& L = lds[wv];
+    const int g = (int)(A.n_docs - d0 < A.docs_per_wave ? A.n_docs - d0 : A.docs_per_wave);
 
-    const int64_t a0 = A.text_off[d], a1 = A.text_off[d + 1];
-    const int64_t a_end = A.text_off[A.n_docs];
-    int64_t p0 = 0, p1 = 0, p_end = 0;
-    if (A.pair) { p0 = A.pair_off[d]; p1 = A.pair_off[d + 1]; p_end = A.pair_off[A.n_docs]; }
+    Group G{T, L, lane, g, A.dense ? A.ids : A.raw, 0, 0, nullptr, 0, 0, 0, nullptr, 0, 0};
+    if (A.dense) { G.limit = A.max_len - 1; G.stop = A.max_len; }       // position max_len-1 is eos or padding
+    else { G.limit = 0x7FFFFFFF; G.stop = 0x7FFFFFFF; }
 
-    Emit E;
-    E.symout = nullptr;
-    E.pad_id = T.pad_id;
-    E.ntok = 0;
-    if (A.dense) {
-        E.ids = A.ids + d * (int64_t)A.max_len;
-        E.mask = A.mask + d * (int64_t)A.max_len;
-        E.limit = A.max_len - 1;                    // position max_len-1 is eos or padding, never a raw token
-        E.stop = A.max_len;
-    } else {
-        // raw row in the workspace: at most bytes+2 tokens per text
-        const int64_t ro = (a0 - A.text_off[0]) + 2 * d + (A.pair ? (p0 - A.pair_off[0]) + 2 * d : 0);
-        E.ids = A.raw + ro;
-        E.mask = nullptr;
-        E.limit = 0x7FFFFFFF;
-        E.stop = 0x7FFFFFFF;
+    // per-document state: row base, bos (tokenize.py:134-135)
+    const int64_t a_beg = A.text_off[d0], a_end = A.text_off[d0 + g];
+    int64_t my_a = 0, my_p = 0;
+    if (lane <= g) {
+        my_a = A.text_off[d0 + lane];
+        if (A.pair) my_p = A.pair_off[d0 + lane];
     }
-    uint32_t* arenaA = A.arena;
-    uint32_t* arenaB = A.arena ? A.arena + (a_end - A.text_off[0]) - (A.pair ? A.pair_off[0] : 0) : nullptr;
+    if (lane < g) {
+        const int64_t d = d0 + lane;
+        int64_t rb;
+        if (A.dense) rb = d * (int64_t)A.max_len;
+        else rb = (my_a - A.text_off[0]) + 2 * d + (A.pair ? (my_p - A.pair_off[0]) + 2 * d : 0);
+        L.row_base[lane] = rb;
+        L.pad_hit[lane] = 0;
+        L.doc_ntok[lane] = 1;
+        if (0 < G.limit) { G.out[rb] = T.bos_id; if (T.bos_id == T.pad_id) L.pad_hit[lane] = 1; }
+    }
+    if (lane <= g) L.doc_rel[lane] = (uint32_t)(my_a - a_beg);
 
     bool ok = true;
-    emit_uniform(E, T.bos_id, lane);                                          // tokenize.py:134-135
-    ok = encode_text(T, L, A.text, a0, a1, a_end, arenaA ? arenaA - A.text_off[0] : nullptr, E, lane);
+    G.base = A.text; G.B0 = a_beg; G.B1 = a_end; G.buf_end = A.text_off[A.n_docs];
+    G.arena = A.arena ? A.arena - A.text_off[0] : nullptr;
+    ok = group_text(G);
     if (ok) {
-        emit_uniform(E, T.eos_id, lane);
-        if (A.pair) {                                                         // tokenize.py:237-239
-            emit_uniform(E, T.eos_id, lane);
-            if (E.ntok < E.stop) ok = encode_text(T, L, A.pair, p0, p1, p_end, arenaB, E, lane);
-            if (ok) emit_uniform(E, T.eos_id, lane);
+        const int reps = A.pair ? 2 : 1;                                    // tokenize.py:237-239: A eos eos B eos
+        if (lane < g) {
+            int p = L.doc_ntok[lane];
+            for (int k = 0; k < reps; ++k) group_emit(G, lane, p + k, T.eos_id);
+            L.doc_ntok[lane] = p + reps;
+        }
+        if (A.pair) {
+            const int64_t p_beg = A.pair_off[d0], p_end = A.pair_off[d0 + g];
+            if (lane <= g) L.doc_rel[lane] = (uint32_t)(my_p - p_beg);
+            G.base = A.pair; G.B0 = p_beg; G.B1 = p_end; G.buf_end = A.pair_off[A.n_docs];
+            G.arena = A.arena ? A.arena + (A.text_off[A.n_docs] - A.text_off[0]) - A.pair_off[0] : nullptr;
+            ok = group_text(G);
+            if (ok && lane < g) {
+                const int p = L.doc_ntok[lane];
+                group_emit(G, lane, p, T.eos_id);
+                L.doc_ntok[lane] = p + 1;
+            }
         }
     }
     if (!ok) {
-        if (lane == 0) { A.n_real[d] = GZ_DEFERRED; *A.defer_flag = 1; }
+        if (lane < g) A.n_real[d0 + lane] = GZ_DEFERRED;
+        if (lane == 0) *A.defer_flag = 1;
         return;
     }
-    if (A.dense) {
-        // __padding (tokenize.py:141-146) + attention mask (:148-152)
-        const int Lm = A.max_len;
-        const int t = E.ntok < Lm ? E.ntok : Lm;
-        const bool cut = E.ntok >= Lm;
-        for (int i = (cut ? Lm - 1 : t) + lane; i < Lm; i += WAVE) {
-            const int32_t v = cut ? T.eos_id : T.pad_id;
-            E.ids[i] = v;
-            E.mask[i] = v != T.pad_id ? 1 : 0;
+    if (!A.dense) {
+        if (lane < g) A.n_real[d0 + lane] = L.doc_ntok[lane];
+        return;
+    }
+    // ---- __padding (tokenize.py:141-146) + attention mask (:148-152), one row at a time, 16-byte stores ------------
+    const int Lm = A.max_len;
+    for (int j = 0; j < g; ++j) {
+        const int Tn = L.doc_ntok[j];
+        const int t = Tn < Lm ? Tn : Lm;
+        const bool cut = Tn >= Lm;
+        int32_t* ids = A.ids + L.row_base[j];
+        int32_t* mask = A.mask + L.row_base[j];
+        const int32_t tailv = cut ? T.eos_id : T.pad_id;
+        const int first = cut ? Lm - 1 : t;                                 // first position not holding a raw token
+        const bool slow = L.pad_hit[j] != 0 || (cut && T.eos_id == T.pad_id);
+        if ((Lm & 3) == 0) {
+            for (int c = lane; c < Lm / 4; c += WAVE) {
+                const int i0 = 4 * c;
+                if (i0 >= first) *reinterpret_cast<int4*>(ids + i0) = make_int4(tailv, tailv, tailv, tailv);
+                else if (i0 + 4 > first) for (int i = first; i < i0 + 4; ++i) ids[i] = tailv;
+                if (!slow) *reinterpret_cast<int4*>(mask + i0) = make_int4(i0 < t, i0 + 1 < t, i0 + 2 < t, i0 + 3 < t);
+            }
+        } else {
+            for (int i = lane; i < Lm; i += WAVE) {
+                if (i >= first) ids[i] = tailv;
+                if (!slow) mask[i] = i < t ? 1 : 0;
+            }
         }
-        if (lane == 0) A.n_real[d] = t;
-    } else if (lane == 0) {
-        A.n_real[d] = E.ntok;
+        if (slow) {                                                         // a real token equals the pad id
+            __threadfence();
+            for (int i = lane; i < Lm; i += WAVE) {
+                const int32_t v = __builtin_nontemporal_load(ids + i);
+                mask[i] = v != T.pad_id ? 1 : 0;
+            }
+        }
+        if (lane == 0) A.n_real[d0 + j] = t;
     }
 }
 
@@ -688,7 +881,7 @@ __global__ __launch_bounds__(WAVE) void gz_bpe_word_kernel(GzDeviceTables T, con
     __shared__ WaveLds L;
     const int lane = lane_id();
     Emit E;
-    E.ids = nullptr; E.mask = nullptr; E.symout = out; E.limit = cap; E.stop = 0x7FFFFFFF; E.ntok = 0; E.pad_id = T.pad_id;
+    E.ids = nullptr; E.mask = nullptr; E.pad_hit = nullptr; E.symout = out; E.limit = cap; E.stop = 0x7FFFFFFF; E.ntok = 0; E.pad_id = T.pad_id;
     long_word(T, L, word, nbytes, false, arena, E, lane);
     if (lane == 0) *n_out = E.ntok;
 }
@@ -698,7 +891,8 @@ __global__ __launch_bounds__(WAVE) void gz_bpe_word_kernel(GzDeviceTables T, con
 // =================================================================================================================
 void gz_launch_encode(const GzDeviceTables& T, const GzEncodeArgs& A, hipStream_t s)
 {
-    const int64_t blocks = (A.n_docs + WPB - 1) / WPB;
+    const int64_t waves = (A.n_docs + A.docs_per_wave - 1) / A.docs_per_wave;
+    const int64_t blocks = (waves + WPB - 1) / WPB;
     if (blocks > 0) hipLaunchKernelGGL(gz_encode_kernel, dim3((unsigned)blocks), dim3(WAVE * WPB), 0, s, T, A);
 }
 
