@@ -7,8 +7,10 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <mutex>
 #include <new>
+#include <vector>
 
 namespace {
 
@@ -66,7 +68,7 @@ struct gz_ctx {
     bool have_tables = false;
     GzHostTables host;
     GzDeviceTables dev{};
-    DBuf t_pair, t_merges, t_symids, t_bmp, t_astral;
+    DBuf t_pair, t_merges, t_symids, t_bmp, t_astral, t_struct;   // t_struct: device copy of `dev`
 
     // workspace
     DBuf w_text, w_toff, w_pair, w_poff, w_ids, w_mask, w_tt, w_seq, w_rowoff, w_rowlen, w_pairlen, w_nreal,
@@ -89,6 +91,9 @@ struct gz_ctx {
     void* comm = nullptr;
     int rank = 0, world = 1;
 
+    DBuf t_words;
+    int64_t n_words = 0;
+    bool no_words_env = false;           // GZ_WORD_TABLE=0 in the environment
     const int64_t* hint_off = nullptr;   // last device offsets array whose byte total was read back
     int64_t hint_n = -1, hint_bytes = 0;
 };
@@ -156,7 +161,7 @@ int enqueue(gz_ctx* c, bool huge_pass)
     p.A.arena = huge_pass ? (uint32_t*)c->w_arena.p : nullptr;
     HIPCHK(c, hipMemsetAsync(c->w_flags.p, 0, 8, s));      // [0] defer, [1] capacity error
     if (p.timing) HIPCHK(c, hipEventRecord(c->ev[0], s));
-    gz_launch_encode(c->dev, p.A, s);
+    gz_launch_encode((const GzDeviceTables*)c->t_struct.p, p.A, s);
     if (p.timing) HIPCHK(c, hipEventRecord(c->ev[1], s));
     if (p.ragged) {
         gz_launch_rowscan(p.F, (int64_t*)c->w_rowlen.p, s);
@@ -234,6 +239,7 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
     A.n_docs = n_docs; A.dense = dense ? 1 : 0; A.max_len = max_len;
     A.ids = input_ids; A.mask = attention_mask; A.raw = nullptr; A.n_real = n_real;
     A.defer_flag = (int32_t*)c->w_flags.p; A.arena = nullptr; A.huge_pass = 0;
+    A.use_words = (c->dev.words != nullptr && !(flags & GZ_NO_WORD_TABLE) && !c->no_words_env) ? 1 : 0;
     // documents per wave: enough bytes per wave to fill its 1-KiB tiles, enough waves to fill the chip
     if (text_bytes < 0) {
         if (c->hint_off == text_off && c->hint_n == n_docs) text_bytes = c->hint_bytes;   // speed only: a stale hint is harmless
@@ -253,6 +259,9 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
         if (dpw < 1) dpw = 1;
         if (dpw > GZ_MAX_DOCS_PER_WAVE) dpw = GZ_MAX_DOCS_PER_WAVE;
         A.docs_per_wave = (int32_t)dpw;
+        if (const char* e = getenv("GZ_DOCS_PER_WAVE")) { int v = atoi(e); if (v >= 1 && v <= GZ_MAX_DOCS_PER_WAVE) A.docs_per_wave = v; }
+        const char* ab = getenv("GZ_ABLATE");       // timing diagnostics only: results are wrong when set
+        A.ablate = ab ? atoi(ab) : 0;
     }
     if (!dense) {
         if (raw_elems < 0) {
@@ -292,6 +301,67 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
 
 }  // namespace
 
+
+static int encode_host_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off, const uint8_t* pair,
+                    const int64_t* pair_off, int64_t n_docs, int32_t max_len, uint32_t flags, int64_t capacity,
+                    int32_t* input_ids, int32_t* attention_mask, int32_t* token_type_ids, int32_t* sequence_id,
+                    int64_t* row_off, int32_t* pair_len, int32_t* n_real, int32_t* status);
+
+// Whole-word table.  Candidates are the merge-closure symbols that end a word (".....</w>", <= 16 bytes without the
+// marker).  Each candidate is tokenized BY THE GPU MERGE PATH ITSELF (one tiny document per word, table disabled);
+// a word whose result is exactly [bos, id, eos] is recorded as word -> id.  Nothing is computed on the CPU.
+static int build_word_table(gz_ctx* c)
+{
+    GzHostTables& H = c->host;
+    std::vector<uint8_t> text;
+    std::vector<int64_t> off(1, 0);
+    std::vector<uint32_t> which;
+    for (size_t s = 0; s < H.symbols.size(); ++s) {
+        const std::string& str = H.symbols[s];
+        if (str.size() < 5 || str.size() > 20 || str.compare(str.size() - 4, 4, "</w>") != 0) continue;
+        const size_t n = str.size() - 4;
+        if (!gz_is_plain_word((const uint8_t*)str.data(), n)) continue;     // contains whitespace: never one word
+        text.insert(text.end(), str.begin(), str.begin() + n);
+        off.push_back((int64_t)text.size());
+        which.push_back((uint32_t)s);
+    }
+    const int64_t n = (int64_t)which.size();
+    if (n == 0) return GZ_OK;
+    const int64_t cap = (int64_t)text.size() + 2 * n;
+    std::vector<int32_t> ids((size_t)cap), mask((size_t)cap), nreal((size_t)n);
+    std::vector<int64_t> row((size_t)n + 1);
+    int rc = encode_host_locked(c, text.data(), off.data(), nullptr, nullptr, n, 0, GZ_MAX_LEN_NONE | GZ_NO_WORD_TABLE, cap,
+                                ids.data(), mask.data(), nullptr, nullptr, row.data(), nullptr, nreal.data(), nullptr);
+    if (rc) return rc;
+    std::vector<GzWordSlot> found;
+    for (int64_t i = 0; i < n; ++i) {
+        if (row[i + 1] - row[i] != 3) continue;
+        const int32_t id = ids[row[i] + 1];
+        if (id < 0 || id >= (1 << 26)) continue;
+        GzWordSlot e{0, 0, (uint32_t)(off[i + 1] - off[i]), id, {0, 0}};
+        uint8_t key[16] = {0};
+        std::memcpy(key, text.data() + off[i], e.len);
+        std::memcpy(&e.lo, key, 8); std::memcpy(&e.hi, key + 8, 8);
+        found.push_back(e);
+    }
+    if (found.empty()) return GZ_OK;
+    size_t slots = 16;
+    while (slots < 2 * found.size()) slots <<= 1;
+    std::vector<GzWordSlot> tab(slots, GzWordSlot{0, 0, 0, 0, {0, 0}});
+    for (const GzWordSlot& e : found) {
+        size_t h = gz_word_hash(e.lo, e.hi, e.len) & (slots - 1);
+        while (tab[h].len != 0) h = (h + 1) & (slots - 1);
+        tab[h] = e;
+    }
+    if ((rc = upload(c, c->t_words, tab))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->dev.words = (const GzWordSlot*)c->t_words.p;
+    c->dev.word_mask = (uint32_t)slots - 1;
+    HIPCHK(c, hipMemcpy(c->t_struct.p, &c->dev, sizeof(GzDeviceTables), hipMemcpyHostToDevice));
+    c->n_words = (int64_t)found.size();
+    return GZ_OK;
+}
+
 // =================================================================================================================
 extern "C" {
 
@@ -320,6 +390,7 @@ int gz_create(int device_id, gz_ctx** out)
         return fail(nullptr, GZ_E_HIP, "stream / pinned memory creation failed");
     }
     std::memset(c->h_flags, 0, 64);
+    if (const char* e = getenv("GZ_WORD_TABLE")) c->no_words_env = (e[0] == '0');
     for (auto& ev : c->ev) hipEventCreate(&ev);
     if (ensure(c, c->w_flags, 64) != GZ_OK) { g_create_err = c->err; gz_destroy(c); return GZ_E_NOMEM; }
     *out = c;
@@ -332,7 +403,7 @@ void gz_destroy(gz_ctx* c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
-    for (DBuf* b : {&c->t_pair, &c->t_merges, &c->t_symids, &c->t_bmp, &c->t_astral, &c->w_text, &c->w_toff, &c->w_pair,
+    for (DBuf* b : {&c->t_pair, &c->t_merges, &c->t_symids, &c->t_bmp, &c->t_astral, &c->t_struct, &c->t_words, &c->w_text, &c->w_toff, &c->w_pair,
                     &c->w_poff, &c->w_ids, &c->w_mask, &c->w_tt, &c->w_seq, &c->w_rowoff, &c->w_rowlen, &c->w_pairlen,
                     &c->w_nreal, &c->w_status, &c->w_raw, &c->w_arena, &c->w_flags, &c->w_word, &c->w_wordout})
         release(*b);
@@ -378,7 +449,13 @@ int gz_load_tables(gz_ctx* c, const uint8_t* vocab, size_t vocab_len, const uint
     D.astral = H.astral.empty() ? nullptr : (const GzAstral*)c->t_astral.p;
     D.astral_mask = H.astral.empty() ? 0 : (uint32_t)H.astral.size() - 1;
     D.pad_id = H.special_ids[0]; D.bos_id = H.special_ids[1]; D.eos_id = H.special_ids[2]; D.unk_id = H.special_ids[4];
+    D.words = nullptr; D.word_mask = 0;
+    if (c->host.enc_words.size() >= (1u << 26)) return fail(c, GZ_E_LIMIT, "vocab has 2^26 or more entries");
+    if ((rc = ensure(c, c->t_struct, sizeof(GzDeviceTables)))) return rc;
+    HIPCHK(c, hipMemcpy(c->t_struct.p, &c->dev, sizeof(GzDeviceTables), hipMemcpyHostToDevice));
     c->have_tables = true;
+    rc = build_word_table(c);
+    if (rc) { c->have_tables = false; return rc; }
     return GZ_OK;
 }
 
@@ -443,14 +520,11 @@ int gz_sync(gz_ctx* c)
     return sync_locked(c);
 }
 
-int gz_encode_batch(gz_ctx* c, const uint8_t* text, const int64_t* text_off, const uint8_t* pair,
+static int encode_host_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off, const uint8_t* pair,
                     const int64_t* pair_off, int64_t n_docs, int32_t max_len, uint32_t flags, int64_t capacity,
                     int32_t* input_ids, int32_t* attention_mask, int32_t* token_type_ids, int32_t* sequence_id,
                     int64_t* row_off, int32_t* pair_len, int32_t* n_real, int32_t* status)
 {
-    if (!c) return GZ_E_INVALID;
-    std::lock_guard<std::mutex> lk(c->mu);
-    HIPCHK(c, hipSetDevice(c->device));
     if (!c->have_tables) return fail(c, GZ_E_NOTABLES, "gz_load_tables has not been called");
     if (n_docs < 0 || !text_off) return fail(c, GZ_E_INVALID, "bad text arguments");
     if ((pair == nullptr) != (pair_off == nullptr) && n_docs > 0)
@@ -537,6 +611,18 @@ int gz_encode_batch(gz_ctx* c, const uint8_t* text, const int64_t* text_off, con
     return GZ_OK;
 }
 
+int gz_encode_batch(gz_ctx* c, const uint8_t* text, const int64_t* text_off, const uint8_t* pair,
+                    const int64_t* pair_off, int64_t n_docs, int32_t max_len, uint32_t flags, int64_t capacity,
+                    int32_t* input_ids, int32_t* attention_mask, int32_t* token_type_ids, int32_t* sequence_id,
+                    int64_t* row_off, int32_t* pair_len, int32_t* n_real, int32_t* status)
+{
+    if (!c) return GZ_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    return encode_host_locked(c, text, text_off, pair, pair_off, n_docs, max_len, flags, capacity, input_ids,
+                              attention_mask, token_type_ids, sequence_id, row_off, pair_len, n_real, status);
+}
+
 int64_t gz_bpe_word(gz_ctx* c, const uint8_t* word, int64_t len, int32_t* pieces, int64_t cap)
 {
     if (!c) return GZ_E_INVALID;
@@ -551,7 +637,7 @@ int64_t gz_bpe_word(gz_ctx* c, const uint8_t* word, int64_t len, int32_t* pieces
     if ((rc = ensure(c, c->w_arena, (size_t)len * 4 + 16))) return rc;
     hipStream_t s = c->stream;
     HIPCHK(c, hipMemcpyAsync(c->w_word.p, word, (size_t)len, hipMemcpyHostToDevice, s));
-    gz_launch_bpe_word(c->dev, (const uint8_t*)c->w_word.p, len, (uint32_t*)c->w_arena.p, (int32_t*)c->w_wordout.p,
+    gz_launch_bpe_word((const GzDeviceTables*)c->t_struct.p, (const uint8_t*)c->w_word.p, len, (uint32_t*)c->w_arena.p, (int32_t*)c->w_wordout.p,
                        (int32_t)len, (int32_t*)c->w_flags.p + 2, s);
     HIPCHK(c, hipMemcpyAsync(c->h_flags + 2, (int32_t*)c->w_flags.p + 2, 4, hipMemcpyDeviceToHost, s));
     HIPCHK(c, hipStreamSynchronize(s));

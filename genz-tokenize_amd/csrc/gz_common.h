@@ -47,6 +47,18 @@ struct GzMergeInfo { uint32_t left, right, merged, pad; };   // indexed by rank
 struct GzSymIds    { int32_t nonfinal, final_; };            // vocab id of  sym+"@@"  /  sym minus "</w>"
 struct GzCpSyms    { uint32_t plain, final_; };              // symbol of  c  /  c+"</w>"   (GZ_NO_SYMBOL if none)
 struct GzAstral    { uint32_t cp, plain, final_, pad; };     // open-addressing entry, cp == GZ_NO_SYMBOL -> empty
+// whole-word table: word bytes (<= 16, zero padded) -> the single vocab id bpe() yields for that word.
+// Built at table-load time by running the GPU merge path itself over every candidate word (gz_api.cpp).
+struct GzWordSlot  { uint64_t lo, hi; uint32_t len; int32_t id; uint32_t pad[2]; };   // len == 0 -> empty
+GZ_HD uint32_t gz_word_hash(uint64_t lo, uint64_t hi, uint32_t len)
+{
+    uint32_t h = (uint32_t)lo * 0x9E3779B1u ^ (uint32_t)(lo >> 32) * 0x85EBCA6Bu ^
+                 (uint32_t)hi * 0xC2B2AE35u ^ (uint32_t)(hi >> 32) * 0x27D4EB2Fu ^ len * 0x165667B1u;
+    h ^= h >> 15;
+    h *= 0x2C1B3C6Du;
+    h ^= h >> 13;
+    return h;
+}
 
 // Device-resident tables, passed to kernels by value.
 struct GzDeviceTables {
@@ -56,6 +68,7 @@ struct GzDeviceTables {
     const GzCpSyms*    bmp;                                   // 65536 entries
     const GzAstral*    astral;      uint32_t astral_mask;    // slots-1; astral == nullptr when no astral symbol exists
     int32_t pad_id, bos_id, eos_id, unk_id;
+    const GzWordSlot*  words;       uint32_t word_mask;      // nullptr until the whole-word table is built
 };
 
 // Host-side result of the loader (tokenize.py:31-57) and of the table build.
@@ -82,3 +95,6 @@ struct GzHostTables {
 // Returns GZ_OK / GZ_E_UTF8 / GZ_E_LIMIT; `err` receives a message.
 int gz_build_tables(const uint8_t* vocab, size_t vocab_len, const uint8_t* bpe, size_t bpe_len,
                     const char* const specials[5], GzHostTables& out, std::string& err);
+
+// true when the n bytes are valid UTF-8 holding no whitespace code point (so the regex "\S+" sees ONE word)
+bool gz_is_plain_word(const uint8_t* p, size_t n);

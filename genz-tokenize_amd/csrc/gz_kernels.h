@@ -29,6 +29,9 @@ struct GzEncodeArgs {
     uint32_t* arena;      // nullptr, or 4 bytes per input byte (text then pair)
     int32_t huge_pass;    // 1: only groups whose first document has n_real == GZ_DEFERRED
     int32_t docs_per_wave; // 1 .. GZ_MAX_DOCS_PER_WAVE (chosen by the host from the average document size)
+    int32_t use_words;     // consult the whole-word table (GzDeviceTables::words)
+    int32_t ablate;        // timing diagnostics only (env GZ_ABLATE; results are WRONG when non-zero): 1 no merge loop,
+                           // 2 no miss decode/merge at all, 4 no token stores, 8 no pad/mask fill, 16 no tile classify
 };
 
 struct GzFinalizeArgs {
@@ -50,9 +53,9 @@ struct GzPairArgs {
     int32_t* seq; int32_t* tt; int32_t* pair_len; int32_t* status;
 };
 
-void gz_launch_encode(const GzDeviceTables& T, const GzEncodeArgs& A, hipStream_t s);
+void gz_launch_encode(const GzDeviceTables* T_dev, const GzEncodeArgs& A, hipStream_t s);   // T_dev: device copy
 void gz_launch_rowscan(const GzFinalizeArgs& F, int64_t* row_len_tmp, hipStream_t s);
 void gz_launch_finalize(const GzDeviceTables& T, const GzFinalizeArgs& F, hipStream_t s);
 void gz_launch_pair(const GzDeviceTables& T, const GzPairArgs& P, hipStream_t s);
-void gz_launch_bpe_word(const GzDeviceTables& T, const uint8_t* word, int64_t nbytes, uint32_t* arena,
+void gz_launch_bpe_word(const GzDeviceTables* T_dev, const uint8_t* word, int64_t nbytes, uint32_t* arena,
                         int32_t* out, int32_t cap, int32_t* n_out, hipStream_t s);

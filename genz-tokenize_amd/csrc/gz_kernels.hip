@@ -164,8 +164,9 @@ __device__ __forceinline__ void emit_uniform(Emit& E, int32_t id, int lane)
 // ---------------------------------------------------------------------------------------------------------------
 // Wave-cooperative merge loop over S[0..n) (LDS or global scratch).  tokenize.py:69-98.
 // ---------------------------------------------------------------------------------------------------------------
-__device__ int wave_merge(const GzDeviceTables& T, uint32_t* S, int n, int lane, bool global_scratch)
+__device__ __noinline__ int wave_merge(const GzDeviceTables* Tp, uint32_t* S, int n, int lane, bool global_scratch)
 {
+    const GzDeviceTables& T = *Tp;
     while (n > 1) {
         uint32_t best = GZ_RANK_NONE;
         for (int i = lane; i < n - 1; i += WAVE) {
@@ -208,10 +209,11 @@ __device__ int wave_merge(const GzDeviceTables& T, uint32_t* S, int n, int lane,
 }
 
 // One word too long for a lane (or for a tile): bytes g[0..nbytes) in global memory, optional glued '\n'.
-// Returns false when the word needs the global arena and none was given (document is deferred).
-__device__ bool long_word(const GzDeviceTables& T, WaveLds& L, const uint8_t* g, int64_t nbytes, bool glue,
-                          uint32_t* arena_slot, Emit& E, int lane)
+// Returns the new token count, or -1 when the word needs the global arena and none was given (deferred).
+__device__ __noinline__ int long_word(const GzDeviceTables* Tp, WaveLds& L, const uint8_t* g, int64_t nbytes, bool glue,
+                                     uint32_t* arena_slot, Emit E, int lane)
 {
+    const GzDeviceTables& T = *Tp;
     auto at = [&](int64_t i) -> uint32_t { return g[i]; };
     int leads = 0;
     for (int64_t i = lane; i < nbytes; i += WAVE) leads += (g[i] & 0xC0) != 0x80;
@@ -220,7 +222,7 @@ __device__ bool long_word(const GzDeviceTables& T, WaveLds& L, const uint8_t* g,
     bool global_scratch = false;
     if (nsym64 <= LONGCAP) S = L.sym;
     else if (arena_slot != nullptr) { S = arena_slot; global_scratch = true; }
-    else return false;
+    else return -1;
     int n = (int)nsym64;
     int symbase = 0;
     for (int64_t base = 0; base < nbytes; base += WAVE) {
@@ -237,7 +239,7 @@ __device__ bool long_word(const GzDeviceTables& T, WaveLds& L, const uint8_t* g,
     }
     if (glue && lane == 0) S[n - 1] = initial_symbol(T, 0x0Au, true);
     if (global_scratch) __threadfence();
-    if (n > 1) n = wave_merge(T, S, n, lane, global_scratch);
+    if (n > 1) n = wave_merge(Tp, S, n, lane, global_scratch);
     for (int base = 0; base < n; base += WAVE) {
         const int i = base + lane;
         if (i < n) {
@@ -245,8 +247,7 @@ __device__ bool long_word(const GzDeviceTables& T, WaveLds& L, const uint8_t* g,
             else emit_at(E, E.ntok + i, token_id(T, S[i], i == n - 1));
         }
     }
-    E.ntok += n;
-    return true;
+    return E.ntok + n;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -346,7 +347,7 @@ __device__ __forceinline__ void load_tile(const uint8_t* base, int64_t pos, int6
 // prefix sum per document (bos/eos framing and truncation: tokenize.py:126-146).
 // ---------------------------------------------------------------------------------------------------------------
 struct Group {
-    const GzDeviceTables& T;
+    const GzDeviceTables* Tp;
     WaveLds& L;
     int lane;
     int g;                    // documents in this group
@@ -356,13 +357,16 @@ struct Group {
     int64_t B0, B1, buf_end;  // byte range of the group in `base`, end of the whole buffer
     uint32_t* arena;          // nullptr or global scratch indexed like `base`
     int nrec, nmiss;          // buffered records / misses (wave-uniform)
+    int ablate;
+    const GzWordSlot* words;  // whole-word table or nullptr
+    uint32_t word_mask;
 };
 
 __device__ __forceinline__ void group_emit(Group& G, int doc, int pos, int32_t id)
 {
-    if (pos < G.limit) {
+    if (pos < G.limit && !(G.ablate & 4)) {
         G.out[G.L.row_base[doc] + pos] = id;
-        if (id == G.T.pad_id) G.L.pad_hit[doc] = 1;
+        if (id == G.Tp->pad_id) G.L.pad_hit[doc] = 1;
     }
 }
 
@@ -410,32 +414,30 @@ __device__ __forceinline__ int lane_merge(const GzDeviceTables& T, WaveLds& L, i
 }
 
 // Turn the buffered records into tokens in their rows.
-__device__ void group_flush(Group& G)
+__device__ __forceinline__ void group_flush(Group& G)
 {
     WaveLds& L = G.L;
-    const GzDeviceTables& T = G.T;
+    const GzDeviceTables& T = *G.Tp;
     const int lane = G.lane;
-    if (G.nrec == 0) return;
     // ---- the misses: decode, merge, look up (one lane per word) ---------------------------------------------------
-    if (G.nmiss > 0) {
-        if (lane < G.nmiss) {
-            const uint8_t* g = G.base + G.B0 + L.miss_off[lane];
-            const int nb = L.miss_len[lane] & 0x7FFF;
-            const bool glue = (L.miss_len[lane] >> 15) != 0;
-            auto at = [&](int64_t i) -> uint32_t { return g[i]; };
-            int n = 0, i = 0;
-            while (i < nb) {
-                int len;
-                const uint32_t cp = decode_cp(at, i, nb, len);
-                L.sym[n * WAVE + lane] = initial_symbol(T, cp, !glue && i + len >= nb);
-                ++n;
-                i += len;
-            }
-            if (glue) { L.sym[n * WAVE + lane] = initial_symbol(T, 0x0Au, true); ++n; }
-            n = lane_merge(T, L, lane, n);
-            for (int k = 0; k < n; ++k) L.sym[k * WAVE + lane] = (uint32_t)token_id(T, L.sym[k * WAVE + lane], k == n - 1);
-            L.miss_ntok[lane] = (uint8_t)n;
+    if (lane < G.nmiss && (G.ablate & 2)) L.miss_ntok[lane] = 1;
+    if (lane < G.nmiss && !(G.ablate & 2)) {
+        const uint8_t* g = G.base + G.B0 + L.miss_off[lane];
+        const int nb = L.miss_len[lane] & 0x7FFF;
+        const bool glue = (L.miss_len[lane] >> 15) != 0;
+        auto at = [&](int64_t i) -> uint32_t { return g[i]; };
+        int n = 0, i = 0;
+        while (i < nb) {
+            int len;
+            const uint32_t cp = decode_cp(at, i, nb, len);
+            L.sym[n * WAVE + lane] = initial_symbol(T, cp, !glue && i + len >= nb);
+            ++n;
+            i += len;
         }
+        if (glue) { L.sym[n * WAVE + lane] = initial_symbol(T, 0x0Au, true); ++n; }
+        if (!(G.ablate & 1)) n = lane_merge(T, L, lane, n);
+        for (int k = 0; k < n; ++k) L.sym[k * WAVE + lane] = (uint32_t)token_id(T, L.sym[k * WAVE + lane], k == n - 1);
+        L.miss_ntok[lane] = (uint8_t)n;
     }
     // ---- positions: segmented exclusive prefix sum of the token counts, one segment per document -----------------
     for (int c0 = 0; c0 < G.nrec; c0 += WAVE) {
@@ -466,20 +468,20 @@ __device__ void group_flush(Group& G)
     G.nmiss = 0;
 }
 
-// a word that does not fit a lane: flush what precedes it, then merge it wave-cooperatively and emit directly
-__device__ bool group_long_word(Group& G, int64_t gpos, int64_t nbytes, bool glue)
+// a word that does not fit a lane: (everything before it has been flushed) merge it wave-cooperatively, emit directly
+__device__ __forceinline__ bool group_long_word(Group& G, int64_t gpos, int64_t nbytes, bool glue)
 {
-    group_flush(G);
     const int doc = doc_of(G, (uint32_t)(gpos - G.B0));
     Emit E;
     E.ids = G.out + G.L.row_base[doc];
     E.mask = nullptr; E.symout = nullptr;
-    E.limit = G.limit; E.stop = G.stop; E.pad_id = G.T.pad_id;
+    E.limit = G.limit; E.stop = G.stop; E.pad_id = G.Tp->pad_id;
     E.pad_hit = &G.L.pad_hit[doc];
     E.ntok = G.L.doc_ntok[doc];
     if (E.ntok < G.stop) {
-        if (!long_word(G.T, G.L, G.base + gpos, nbytes, glue, G.arena ? G.arena + gpos : nullptr, E, G.lane)) return false;
-        if (G.lane == 0) G.L.doc_ntok[doc] = E.ntok;
+        const int nt = long_word(G.Tp, G.L, G.base + gpos, nbytes, glue, G.arena ? G.arena + gpos : nullptr, E, G.lane);
+        if (nt < 0) return false;
+        if (G.lane == 0) G.L.doc_ntok[doc] = nt;
     }
     return true;
 }
@@ -502,13 +504,14 @@ __device__ __forceinline__ void group_tile(Group& G, int64_t pos, bool prev_ws0,
 
 // One text (A or B) of every document of the group: __tokenize + ids (tokenize.py:103-133).
 // Returns false if the group must be deferred to the arena pass.
-__device__ bool group_text(Group& G)
+__device__ __forceinline__ bool group_text(Group& G)
 {
     WaveLds& L = G.L;
-    const GzDeviceTables& T = G.T;
     const int lane = G.lane;
     const uint8_t* lds_bytes = reinterpret_cast<const uint8_t*>(L.bytes);
     int64_t pos = G.B0;
+    // a giant word (one that fills a whole tile) is handled by the same flush + long-word site as ordinary long
+    // words: `giant_len` >= 0 asks for it at the top of the next round iteration
     while (pos < G.B1) {
         uint32_t st16, en16;
         group_tile(G, pos, true, st16, en16);
@@ -518,11 +521,38 @@ __device__ bool group_text(Group& G)
         for (uint32_t m = st16; m; m &= m - 1) L.wstart[sidx++] = (uint16_t)(16 * lane + __ffs(m) - 1);
         for (uint32_t m = en16; m; m &= m - 1) L.wend[eidx++] = (uint16_t)(16 * lane + __ffs(m) - 1);
         const uint32_t tile_rel = (uint32_t)(pos - G.B0);
-
         const int nw = n_ends;                                  // complete words of this tile
-        for (int wbase = 0; wbase < nw; wbase += WAVE) {
-            const int wi = wbase + lane;
-            bool have = wi < nw;
+
+        // a word that fills the whole tile: find its end by scanning forward, then treat it as one long word
+        int64_t giant_len = -1;
+        bool giant_glue = false;
+        if (n_starts > n_ends && nw == 0 && L.wstart[0] == 0) {
+            int64_t q = pos + TILE;
+            int64_t wend_abs = G.B1;
+            bool at_break = false;
+            while (q < G.B1) {
+                uint32_t s2, e2;
+                group_tile(G, q, false, s2, e2);
+                const uint64_t any = __ballot(e2 != 0);
+                if (any) {
+                    const int fl = __ffsll((unsigned long long)any) - 1;
+                    const uint32_t eb = (uint32_t)__shfl((int)e2, fl, WAVE);
+                    const int p = 16 * fl + __ffs(eb) - 1;
+                    wend_abs = q + p;
+                    at_break = ((L.brk[p >> 5] >> (p & 31)) & 1u) != 0;
+                    break;
+                }
+                q += TILE;
+            }
+            if (wend_abs > G.B1) wend_abs = G.B1;
+            giant_glue = wend_abs < G.B1 && !at_break && G.base[wend_abs] == 0x0A;
+            giant_len = wend_abs - pos;
+        }
+
+        const int nrounds = giant_len >= 0 ? 1 : (nw + WAVE - 1) / WAVE;
+        for (int rd = 0; rd < nrounds; ++rd) {
+            const int wi = rd * WAVE + lane;
+            bool have = giant_len < 0 && wi < nw;
             const int ws = have ? L.wstart[wi] : 0;
             const int we = have ? L.wend[wi] : 0;
             const bool glue = have && lds_bytes[we] == 0x0Au && !((L.brk[we >> 5] >> (we & 31)) & 1u);   // "\S+\n?"
@@ -536,11 +566,40 @@ __device__ bool group_text(Group& G)
                 for (int i = ws; i < we; ++i) leads += (lds_bytes[i] & 0xC0u) != 0x80u;
                 is_long = leads > MAXSYM;
             }
-            const bool hit = false;
-            const uint32_t hit_id = 0;
+            // whole-word table: a plain word of <= 16 bytes whose bpe() is known to be ONE piece needs no merge loop
+            bool hit = false;
+            uint32_t hit_id = 0;
+            if (G.words != nullptr && have && !glue && nb <= 16) {
+                const uint64_t* q = reinterpret_cast<const uint64_t*>(L.bytes) + (ws >> 3);
+                const uint64_t x0 = q[0], x1 = q[1], x2 = q[2];
+                const int sh = (ws & 7) * 8;
+                uint64_t lo = sh ? (x0 >> sh) | (x1 << (64 - sh)) : x0;
+                uint64_t hi = sh ? (x1 >> sh) | (x2 << (64 - sh)) : x1;
+                if (nb <= 8) { hi = 0; if (nb < 8) lo &= (1ull << (8 * nb)) - 1ull; }
+                else if (nb < 16) hi &= (1ull << (8 * (nb - 8))) - 1ull;
+                uint32_t h = gz_word_hash(lo, hi, (uint32_t)nb) & G.word_mask;
+                for (;;) {
+                    const GzWordSlot e = G.words[h];
+                    if (e.len == (uint32_t)nb && e.lo == lo && e.hi == hi) { hit = true; hit_id = (uint32_t)e.id; break; }
+                    if (e.len == 0) break;
+                    h = (h + 1) & G.word_mask;
+                }
+            }
             // append in word order; a lane that does not fit (or is long) cuts the round: flush, then go on
             int lo = 0;
+            bool need_flush = giant_len >= 0;
+            int64_t lw_pos = pos, lw_len = giant_len;            // pending long word (after the flush)
+            bool lw_glue = giant_glue;
             for (;;) {
+                if (need_flush) {
+                    if (G.nrec > 0) group_flush(G);
+                    need_flush = false;
+                    if (lw_len >= 0) {
+                        if (!group_long_word(G, lw_pos, lw_len, lw_glue)) return false;
+                        lw_len = -1;
+                    }
+                    if (giant_len >= 0) break;
+                }
                 const bool rem = have && lane >= lo;
                 const bool missr = rem && !hit && !is_long;
                 const uint64_t remb = __ballot(rem), missb = __ballot(missr);
@@ -564,48 +623,22 @@ __device__ bool group_text(Group& G)
                 G.nrec += __popcll(__ballot(app));
                 G.nmiss += __popcll(__ballot(app && missr));
                 if (cut == WAVE) break;
+                need_flush = true;
                 if (__shfl((int)is_long, cut, WAVE)) {
-                    const int fs = __shfl(ws, cut, WAVE), fe = __shfl(we, cut, WAVE);
-                    const bool fg = __shfl((int)glue, cut, WAVE) != 0;
-                    if (!group_long_word(G, pos + fs, fe - fs, fg)) return false;
+                    lw_pos = pos + __shfl(ws, cut, WAVE);
+                    lw_len = __shfl(nb, cut, WAVE);
+                    lw_glue = __shfl((int)glue, cut, WAVE) != 0;
                     lo = cut + 1;
                 } else {
-                    group_flush(G);
                     lo = cut;
                 }
             }
         }
 
-        if (n_starts > n_ends) {
-            const int s_last = L.wstart[n_ends];
-            if (s_last > 0) { pos += s_last; continue; }        // re-tile at the start of the cut word
-            // a word that fills the whole tile: find its end by scanning forward
-            int64_t q = pos + TILE;
-            int64_t wend_abs = G.B1;
-            bool at_break = false;
-            while (q < G.B1) {
-                uint32_t s2, e2;
-                group_tile(G, q, false, s2, e2);
-                const uint64_t any = __ballot(e2 != 0);
-                if (any) {
-                    const int fl = __ffsll((unsigned long long)any) - 1;
-                    const uint32_t eb = (uint32_t)__shfl((int)e2, fl, WAVE);
-                    const int p = 16 * fl + __ffs(eb) - 1;
-                    wend_abs = q + p;
-                    at_break = ((L.brk[p >> 5] >> (p & 31)) & 1u) != 0;
-                    break;
-                }
-                q += TILE;
-            }
-            if (wend_abs > G.B1) wend_abs = G.B1;
-            const bool fg = wend_abs < G.B1 && !at_break && G.base[wend_abs] == 0x0A;
-            if (!group_long_word(G, pos, wend_abs - pos, fg)) return false;
-            pos = wend_abs + (fg ? 1 : 0);
-        } else {
-            pos += TILE;
-        }
+        if (giant_len >= 0) pos += giant_len + (giant_glue ? 1 : 0);
+        else if (n_starts > n_ends) pos += L.wstart[n_ends];        // re-tile at the start of the cut word (> 0 here)
+        else pos += TILE;
     }
-    group_flush(G);
     return true;
 }
 
@@ -614,9 +647,10 @@ __device__ bool group_text(Group& G)
 // =================================================================================================================
 // gz_encode_kernel
 // =================================================================================================================
-__global__ __launch_bounds__(WAVE * WPB) void gz_encode_kernel(GzDeviceTables T, GzEncodeArgs A)
+__global__ __launch_bounds__(WAVE * WPB) void gz_encode_kernel(const GzDeviceTables* __restrict__ Tp, GzEncodeArgs A)
 {
     __shared__ WaveLds lds[WPB];
+    const GzDeviceTables& T = *Tp;
     const int lane = lane_id();
     const int wv = threadIdx.x / WAVE;
     const int64_t d0 = ((int64_t)blockIdx.x * WPB + wv) * A.docs_per_wave;
@@ -625,12 +659,12 @@ __global__ __launch_bounds__(WAVE * WPB) void gz_encode_kernel(GzDeviceTables T,
     WaveLds& L = lds[wv];
     const int g = (int)(A.n_docs - d0 < A.docs_per_wave ? A.n_docs - d0 : A.docs_per_wave);
 
-    Group G{T, L, lane, g, A.dense ? A.ids : A.raw, 0, 0, nullptr, 0, 0, 0, nullptr, 0, 0};
+    Group G{Tp, L, lane, g, A.dense ? A.ids : A.raw, 0, 0, nullptr, 0, 0, 0, nullptr, 0, 0, A.ablate,
+            A.use_words ? T.words : nullptr, T.word_mask};
     if (A.dense) { G.limit = A.max_len - 1; G.stop = A.max_len; }       // position max_len-1 is eos or padding
     else { G.limit = 0x7FFFFFFF; G.stop = 0x7FFFFFFF; }
 
     // per-document state: row base, bos (tokenize.py:134-135)
-    const int64_t a_beg = A.text_off[d0], a_end = A.text_off[d0 + g];
     int64_t my_a = 0, my_p = 0;
     if (lane <= g) {
         my_a = A.text_off[d0 + lane];
@@ -646,30 +680,26 @@ __global__ __launch_bounds__(WAVE * WPB) void gz_encode_kernel(GzDeviceTables T,
         L.doc_ntok[lane] = 1;
         if (0 < G.limit) { G.out[rb] = T.bos_id; if (T.bos_id == T.pad_id) L.pad_hit[lane] = 1; }
     }
-    if (lane <= g) L.doc_rel[lane] = (uint32_t)(my_a - a_beg);
 
     bool ok = true;
-    G.base = A.text; G.B0 = a_beg; G.B1 = a_end; G.buf_end = A.text_off[A.n_docs];
-    G.arena = A.arena ? A.arena - A.text_off[0] : nullptr;
-    ok = group_text(G);
-    if (ok) {
-        const int reps = A.pair ? 2 : 1;                                    // tokenize.py:237-239: A eos eos B eos
+    const int ntexts = A.pair ? 2 : 1;
+    for (int tx = 0; tx < ntexts && ok; ++tx) {
+        const int64_t* off = tx ? A.pair_off : A.text_off;
+        const int64_t beg = off[d0];
+        G.base = tx ? A.pair : A.text;
+        G.B0 = beg; G.B1 = off[d0 + g]; G.buf_end = off[A.n_docs];
+        G.arena = nullptr;
+        if (A.arena) G.arena = tx ? A.arena + (A.text_off[A.n_docs] - A.text_off[0]) - A.pair_off[0] : A.arena - A.text_off[0];
+        if (lane <= g) L.doc_rel[lane] = (uint32_t)((tx ? my_p : my_a) - beg);
+        ok = group_text(G);
+        if (!ok) break;
+        if (G.nrec > 0) group_flush(G);
+        // A eos [eos B eos]   (tokenize.py:134-135, :237-239)
+        const int reps = (A.pair && tx == 0) ? 2 : 1;
         if (lane < g) {
-            int p = L.doc_ntok[lane];
+            const int p = L.doc_ntok[lane];
             for (int k = 0; k < reps; ++k) group_emit(G, lane, p + k, T.eos_id);
             L.doc_ntok[lane] = p + reps;
-        }
-        if (A.pair) {
-            const int64_t p_beg = A.pair_off[d0], p_end = A.pair_off[d0 + g];
-            if (lane <= g) L.doc_rel[lane] = (uint32_t)(my_p - p_beg);
-            G.base = A.pair; G.B0 = p_beg; G.B1 = p_end; G.buf_end = A.pair_off[A.n_docs];
-            G.arena = A.arena ? A.arena + (A.text_off[A.n_docs] - A.text_off[0]) - A.pair_off[0] : nullptr;
-            ok = group_text(G);
-            if (ok && lane < g) {
-                const int p = L.doc_ntok[lane];
-                group_emit(G, lane, p, T.eos_id);
-                L.doc_ntok[lane] = p + 1;
-            }
         }
     }
     if (!ok) {
@@ -683,6 +713,7 @@ __global__ __launch_bounds__(WAVE * WPB) void gz_encode_kernel(GzDeviceTables T,
     }
     // ---- __padding (tokenize.py:141-146) + attention mask (:148-152), one row at a time, 16-byte stores ------------
     const int Lm = A.max_len;
+    if (A.ablate & 8) return;
     for (int j = 0; j < g; ++j) {
         const int Tn = L.doc_ntok[j];
         const int t = Tn < Lm ? Tn : Lm;
@@ -875,21 +906,21 @@ __global__ __launch_bounds__(WAVE * WPB) void gz_pair_kernel(GzDeviceTables T, G
 // =================================================================================================================
 // gz_bpe_word_kernel: Tokenize.bpe(token) -- the whole input is ONE word (no whitespace split, no glue)
 // =================================================================================================================
-__global__ __launch_bounds__(WAVE) void gz_bpe_word_kernel(GzDeviceTables T, const uint8_t* word, int64_t nbytes,
+__global__ __launch_bounds__(WAVE) void gz_bpe_word_kernel(const GzDeviceTables* __restrict__ Tp, const uint8_t* word, int64_t nbytes,
                                                             uint32_t* arena, int32_t* out, int32_t cap, int32_t* n_out)
 {
     __shared__ WaveLds L;
     const int lane = lane_id();
     Emit E;
-    E.ids = nullptr; E.mask = nullptr; E.pad_hit = nullptr; E.symout = out; E.limit = cap; E.stop = 0x7FFFFFFF; E.ntok = 0; E.pad_id = T.pad_id;
-    long_word(T, L, word, nbytes, false, arena, E, lane);
-    if (lane == 0) *n_out = E.ntok;
+    E.ids = nullptr; E.mask = nullptr; E.pad_hit = nullptr; E.symout = out; E.limit = cap; E.stop = 0x7FFFFFFF; E.ntok = 0; E.pad_id = Tp->pad_id;
+    const int nt = long_word(Tp, L, word, nbytes, false, arena, E, lane);
+    if (lane == 0) *n_out = nt;
 }
 
 // =================================================================================================================
 // launchers
 // =================================================================================================================
-void gz_launch_encode(const GzDeviceTables& T, const GzEncodeArgs& A, hipStream_t s)
+void gz_launch_encode(const GzDeviceTables* T, const GzEncodeArgs& A, hipStream_t s)
 {
     const int64_t waves = (A.n_docs + A.docs_per_wave - 1) / A.docs_per_wave;
     const int64_t blocks = (waves + WPB - 1) / WPB;
@@ -916,7 +947,7 @@ void gz_launch_pair(const GzDeviceTables& T, const GzPairArgs& P, hipStream_t s)
     hipLaunchKernelGGL(gz_pair_kernel, dim3((unsigned)((P.n_docs + WPB - 1) / WPB)), dim3(WAVE * WPB), 0, s, T, P);
 }
 
-void gz_launch_bpe_word(const GzDeviceTables& T, const uint8_t* word, int64_t nbytes, uint32_t* arena,
+void gz_launch_bpe_word(const GzDeviceTables* T, const uint8_t* word, int64_t nbytes, uint32_t* arena,
                         int32_t* out, int32_t cap, int32_t* n_out, hipStream_t s)
 {
     hipLaunchKernelGGL(gz_bpe_word_kernel, dim3(1), dim3(WAVE), 0, s, T, word, nbytes, arena, out, cap, n_out);

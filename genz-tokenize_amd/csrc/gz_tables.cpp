@@ -135,6 +135,14 @@ struct OrderedDict {            // a Python dict[str, int]: insertion order, ove
 
 }  // namespace
 
+bool gz_is_plain_word(const uint8_t* p, size_t n)
+{
+    U32 cps;
+    if (n == 0 || !decode_utf8_strict(p, n, cps)) return false;
+    for (char32_t c : cps) if (is_space(c)) return false;
+    return true;
+}
+
 int gz_build_tables(const uint8_t* vocab, size_t vocab_len, const uint8_t* bpe, size_t bpe_len,
                     const char* const specials[5], GzHostTables& T, std::string& err)
 {

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libgenz_tokenize_hip.so")
 
 GZ_OK, GZ_E_INVALID, GZ_E_UTF8, GZ_E_HIP, GZ_E_NOTABLES = 0, -1, -2, -3, -4
 GZ_E_CAPACITY, GZ_E_LIMIT, GZ_E_NOMEM, GZ_E_RCCL, GZ_E_NODEVICE = -5, -6, -7, -8, -9
-GZ_PADDING, GZ_TRUNCATION, GZ_MAX_LEN_NONE, GZ_TIMING = 0x1, 0x2, 0x4, 0x100
+GZ_PADDING, GZ_TRUNCATION, GZ_MAX_LEN_NONE, GZ_TIMING, GZ_NO_WORD_TABLE = 0x1, 0x2, 0x4, 0x100, 0x200
 GZ_NONE = -1
 
 # every symbol include/genz_tokenize.h declares (tests/test_abi.py checks the export list against the header)
@@ -167,11 +167,12 @@ class Context:
         return C.string_at(p, ln.value).decode("utf-8")
 
     # ---- encode, host buffers ------------------------------------------------------------------------------
-    def encode(self, text: np.ndarray, text_off: np.ndarray, pair, pair_off, max_len, padding, truncation):
+    def encode(self, text: np.ndarray, text_off: np.ndarray, pair, pair_off, max_len, padding, truncation,
+               extra_flags: int = 0):
         """Returns dict(input_ids, attention_mask, [token_type_ids, sequence_id, pair_len, status], row_off,
         n_real, dense).  Flat int32 arrays + int64 row offsets."""
         n = len(text_off) - 1
-        flags = (GZ_PADDING if padding else 0) | (GZ_TRUNCATION if truncation else 0)
+        flags = (GZ_PADDING if padding else 0) | (GZ_TRUNCATION if truncation else 0) | extra_flags
         ml = 0
         if max_len is None:
             flags |= GZ_MAX_LEN_NONE

@@ -144,13 +144,14 @@ class Tokenize(object):
         return "@@ ".join(strs)[:-4]
 
     # ---- encode / decode -------------------------------------------------------------------------------------
-    def _run(self, texts, pairs, max_len, padding, truncation):
+    def _run(self, texts, pairs, max_len, padding, truncation, word_table=True):
         self._sync_tables()
         tb, to = _pack(texts)
         pb = po = None
         if pairs is not None:
             pb, po = _pack(pairs)
-        return self._ctx.encode(tb, to, pb, po, max_len, bool(padding), bool(truncation))
+        return self._ctx.encode(tb, to, pb, po, max_len, bool(padding), bool(truncation),
+                                0 if word_table else _native.GZ_NO_WORD_TABLE)
 
     def encode(self, sentence, return_offset) -> List[int]:
         """tokenize.py:126-135."""
@@ -223,20 +224,25 @@ class Tokenize(object):
 
     # ---- batch API (new) -----------------------------------------------------------------------------------------
     def encode_batch(self, texts: Sequence[str], pair_texts: Optional[Sequence[str]] = None,
-                     max_len: Optional[int] = None, padding: bool = True, truncation: bool = True):
+                     max_len: Optional[int] = None, padding: bool = True, truncation: bool = True,
+                     word_table: bool = True):
         """`__call__` over many documents in one launch.  With max_len >= 1, padding and truncation the result
         arrays are [N, max_len] int32; otherwise they are flat with `row_off` [N+1].  `status[i] == 1` marks a
         document for which the single-call API raises ValueError."""
         if pair_texts is not None and len(pair_texts) != len(texts):
             raise ValueError("texts and pair_texts differ in length")
-        r = self._run(list(texts), None if pair_texts is None else list(pair_texts), max_len, padding, truncation)
+        r = self._run(list(texts), None if pair_texts is None else list(pair_texts), max_len, padding, truncation,
+                      word_table)
         return self._shape(r, len(texts))
 
     def encode_packed(self, text_u8: np.ndarray, offsets: np.ndarray, pair_u8=None, pair_offsets=None,
-                      max_len: Optional[int] = None, padding: bool = True, truncation: bool = True):
-        """Batch call on already packed UTF-8 (uint8 array + int64 offsets[N+1]); skips Python string packing."""
+                      max_len: Optional[int] = None, padding: bool = True, truncation: bool = True,
+                      word_table: bool = True):
+        """Batch call on already packed UTF-8 (uint8 array + int64 offsets[N+1]); skips Python string packing.
+        `word_table=False` makes every word run the merge loop (same results; for tests and measurements)."""
         self._sync_tables()
-        r = self._ctx.encode(text_u8, offsets, pair_u8, pair_offsets, max_len, bool(padding), bool(truncation))
+        r = self._ctx.encode(text_u8, offsets, pair_u8, pair_offsets, max_len, bool(padding), bool(truncation),
+                             0 if word_table else _native.GZ_NO_WORD_TABLE)
         return self._shape(r, len(offsets) - 1)
 
     @staticmethod

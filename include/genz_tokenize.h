@@ -44,6 +44,7 @@ extern "C" {
 #define GZ_TRUNCATION    0x2u   /* truncation=True                                */
 #define GZ_MAX_LEN_NONE  0x4u   /* max_len=None (the max_len argument is ignored) */
 #define GZ_TIMING        0x100u /* record HIP events around the kernels (gz_timing) */
+#define GZ_NO_WORD_TABLE 0x200u /* do not consult the whole-word table: every word runs the merge loop (same results) */
 
 #define GZ_NONE (-1)            /* Python None in sequence_id / token_type_ids */
 

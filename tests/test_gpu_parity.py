@@ -135,8 +135,8 @@ def test_g4_loader(tmp_path):
             _call_matches(t, c)
 
 
-def _check_hashes(tok, e, text, offs):
-    out = tok.encode_packed(text, offs, max_len=e["max_len"])
+def _check_hashes(tok, e, text, offs, word_table=True):
+    out = tok.encode_packed(text, offs, max_len=e["max_len"], word_table=word_table)
     ids, mask = out["input_ids"], out["attention_mask"]
     blk = e["block"]
     for k, lo in enumerate(range(0, e["n_docs"], blk)):
@@ -147,13 +147,15 @@ def _check_hashes(tok, e, text, offs):
     assert int(out["n_real"].sum()) == e["n_tokens"]
 
 
+@pytest.mark.parametrize("word_table", [True, False])
 @pytest.mark.parametrize("name", ["cfg2_10k", "cfg3_20k", "cfg3_1M"])
-def test_g5_reference_hashes_bundled(tok, sampler, name):
-    """BASELINE configs 2 and 3 at FULL size against digests of the reference's own output."""
+def test_g5_reference_hashes_bundled(tok, sampler, name, word_table):
+    """BASELINE configs 2 and 3 at FULL size against digests of the reference's own output, with the whole-word
+    table and with every word going through the merge loop."""
     e = json.load(open(os.path.join(GOLDEN, "g5_hashes.json")))[name]
     text, offs, L = corpus.config_corpus(e["cfg"], n_docs=e["n_docs"], sampler=sampler)
     assert L == e["max_len"]
-    _check_hashes(tok, e, text, offs)
+    _check_hashes(tok, e, text, offs, word_table)
 
 
 def test_g5_reference_hashes_custom_tables(sampler, tmp_path):
@@ -164,7 +166,8 @@ def test_g5_reference_hashes_custom_tables(sampler, tmp_path):
     (tmp_path / "v").write_bytes(v); (tmp_path / "b").write_bytes(b)
     t = Tokenize.fromFile(str(tmp_path / "v"), str(tmp_path / "b"))
     text, offs, L = corpus.config_corpus(5, n_docs=e["n_docs"], sampler=sampler)
-    _check_hashes(t, e, text, offs)
+    _check_hashes(t, e, text, offs, True)
+    _check_hashes(t, e, text, offs, False)
 
 
 def _oracle_rows(t, text, offs, pairs, ml, pad, tr):
@@ -198,8 +201,10 @@ def test_noisy_corpus_vs_oracle(tok, oracle_tables, sampler, shape):
     ml, pad, tr = shape
     text, offs, _ = corpus.config_corpus(2, n_docs=1500, seed=77, sampler=sampler)
     text, offs = corpus.add_noise(text, offs, seed=5, rate=0.06)
-    out = tok.encode_packed(text, offs, max_len=ml, padding=pad, truncation=tr)
-    _compare_batch(out, _oracle_rows(oracle_tables, text, offs, None, ml, pad, tr), False)
+    want = _oracle_rows(oracle_tables, text, offs, None, ml, pad, tr)
+    for wt in (True, False):
+        out = tok.encode_packed(text, offs, max_len=ml, padding=pad, truncation=tr, word_table=wt)
+        _compare_batch(out, want, False)
 
 
 @pytest.mark.parametrize("shape", [(64, True, True), (None, True, True), (24, True, False), (5, True, True), (2, True, True)])
@@ -209,8 +214,10 @@ def test_noisy_pairs_vs_oracle(tok, oracle_tables, sampler, shape):
     tb, ob, _ = corpus.config_corpus(2, n_docs=800, seed=12, sampler=sampler)
     ta, oa = corpus.add_noise(ta, oa, seed=1, rate=0.05)
     tb, ob = corpus.add_noise(tb, ob, seed=2, rate=0.05)
-    out = tok.encode_packed(ta, oa, tb, ob, max_len=ml, padding=pad, truncation=tr)
-    _compare_batch(out, _oracle_rows(oracle_tables, ta, oa, (tb, ob), ml, pad, tr), True)
+    want = _oracle_rows(oracle_tables, ta, oa, (tb, ob), ml, pad, tr)
+    for wt in (True, False):
+        out = tok.encode_packed(ta, oa, tb, ob, max_len=ml, padding=pad, truncation=tr, word_table=wt)
+        _compare_batch(out, want, True)
 
 
 def test_long_and_huge_words(tok, oracle_tables):

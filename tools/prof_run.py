@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Small driver for rocprofv3 (kernel trace or --pmc passes): encodes a cfg-3 corpus a few times through the
+device entry point.  No torch.  usage: prof_run.py [n_docs] [iters] [cfg]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "genz-tokenize_amd"))
+import numpy as np
+import corpus
+from genz_tokenize import Tokenize, _native
+
+n_docs = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+cfg = int(sys.argv[3]) if len(sys.argv) > 3 else 3
+tok = Tokenize(); tok._sync_tables(); ctx = tok._ctx
+text, offs, L = corpus.config_corpus(cfg, n_docs=n_docs)
+n = len(offs) - 1
+d_text = ctx.alloc(len(text) + 64); ctx.h2d(d_text, text)
+d_off = ctx.alloc(8 * (n + 1)); ctx.h2d(d_off, offs)
+d_ids = ctx.alloc(4 * n * L); d_mask = ctx.alloc(4 * n * L); d_nreal = ctx.alloc(4 * n)
+flags = _native.GZ_PADDING | _native.GZ_TRUNCATION | _native.GZ_TIMING
+if os.environ.get("NO_WORD_TABLE"):
+    flags |= _native.GZ_NO_WORD_TABLE
+ms = []
+for _ in range(iters):
+    ctx.encode_device(d_text, d_off, 0, 0, n, L, flags, n * L, d_ids, d_mask, d_n_real=d_nreal)
+    ctx.sync()
+    ms.append(ctx.timing()[0])
+nr = np.empty(n, dtype=np.int32); ctx.d2h(nr, d_nreal)
+print("docs", n, "bytes", len(text), "tokens", int(nr.sum()), "kernel ms", [round(x, 3) for x in ms],
+      "MB/s", round(len(text) / min(ms) / 1e3, 1))
