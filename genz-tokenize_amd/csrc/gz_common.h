@@ -43,6 +43,7 @@ GZ_HD uint32_t gz_cp_hash(uint32_t cp)
     return h ^ (h >> 16);
 }
 
+struct GzPairSlot  { uint64_t keyrank; uint32_t merged; uint32_t pad; };   // keyrank == GZ_PAIR_EMPTY -> empty
 struct GzMergeInfo { uint32_t left, right, merged, pad; };   // indexed by rank
 struct GzSymIds    { int32_t nonfinal, final_; };            // vocab id of  sym+"@@"  /  sym minus "</w>"
 struct GzCpSyms    { uint32_t plain, final_; };              // symbol of  c  /  c+"</w>"   (GZ_NO_SYMBOL if none)
@@ -62,7 +63,7 @@ GZ_HD uint32_t gz_word_hash(uint64_t lo, uint64_t hi, uint32_t len)
 
 // Device-resident tables, passed to kernels by value.
 struct GzDeviceTables {
-    const uint64_t*    pair_tab;    uint32_t pair_mask;      // slots-1 (power of two)
+    const GzPairSlot*  pair_tab;    uint32_t pair_mask;      // slots-1 (power of two)
     const GzMergeInfo* merges;      uint32_t n_ranks;
     const GzSymIds*    sym_ids;     uint32_t n_symbols;
     const GzCpSyms*    bmp;                                   // 65536 entries
@@ -84,7 +85,7 @@ struct GzHostTables {
     // interned symbols
     std::vector<std::string> symbols;
     // device images
-    std::vector<uint64_t>    pair_tab;
+    std::vector<GzPairSlot>  pair_tab;
     std::vector<GzMergeInfo> merges;
     std::vector<GzSymIds>    sym_ids;
     std::vector<GzCpSyms>    bmp;

@@ -25,7 +25,7 @@ constexpr int MAXSYM = 16;                   // symbols a lane-per-word merge ho
 constexpr int LONGCAP = WAVE * MAXSYM;       // symbols the wave-cooperative LDS path holds (same LDS region)
 constexpr int MAXWORDS = TILE / 2 + 1;       // a word needs >= 1 byte + >= 1 whitespace byte
 constexpr int GMAX = GZ_MAX_DOCS_PER_WAVE;   // documents per wave
-constexpr int RECCAP = 1024;                 // word records buffered between two flushes
+constexpr int RECCAP = 512;                  // word records buffered between two flushes
 constexpr int MISSCAP = WAVE;                // words waiting for the merge loop (one lane each)
 constexpr uint32_t REC_MISS = 0x80000000u;   // record = [miss:1][doc:5][payload:26]  payload = vocab id | miss slot
 
@@ -38,8 +38,8 @@ struct alignas(16) WaveLds {
     uint32_t doc_rel[GMAX + 1];              // document starts, relative to the first byte of the wave's range
     int32_t  doc_ntok[GMAX];                 // raw tokens emitted so far per document
     int64_t  row_base[GMAX];                 // element offset of each document's row
+    uint32_t endmap[TILE / 32];              // bit p set = a word ends before byte p of the current tile
     uint16_t wstart[MAXWORDS + 3];
-    uint16_t wend[MAXWORDS + 3];
     uint16_t miss_len[MISSCAP];              // bytes | glue << 15
     uint8_t  miss_ntok[MISSCAP];
     uint8_t  pad_hit[GMAX];                  // a real token of this document equals the pad id (mask needs the slow path)
@@ -84,11 +84,37 @@ __device__ __forceinline__ uint32_t probe_rank(const GzDeviceTables& T, uint32_t
     uint32_t h = gz_pair_hash(a, b) & T.pair_mask;
     const uint64_t key = gz_pair_key(a, b);
     for (;;) {
-        uint64_t e = T.pair_tab[h];
+        uint64_t e = T.pair_tab[h].keyrank;
         if ((e >> 24) == key) return (uint32_t)e & 0xFFFFFFu;
         if (e == GZ_PAIR_EMPTY) return GZ_RANK_NONE;
         h = (h + 1) & T.pair_mask;
     }
+}
+
+// the same probe returning the merged symbol too (one 16-byte load)
+__device__ __forceinline__ uint32_t probe_pair(const GzDeviceTables& T, uint32_t a, uint32_t b, uint32_t& merged)
+{
+    if ((a | b) & 0xFFF00000u) return GZ_RANK_NONE;
+    uint32_t h = gz_pair_hash(a, b) & T.pair_mask;
+    const uint64_t key = gz_pair_key(a, b);
+    for (;;) {
+        const uint4 v = *reinterpret_cast<const uint4*>(&T.pair_tab[h]);
+        const uint64_t e = ((uint64_t)v.y << 32) | v.x;
+        if ((e >> 24) == key) { merged = v.z; return v.x & 0xFFFFFFu; }
+        if (e == GZ_PAIR_EMPTY) return GZ_RANK_NONE;
+        h = (h + 1) & T.pair_mask;
+    }
+}
+
+// minimum over the 16 lanes of a DPP row (quad swaps, then half-row and row mirrors)
+__device__ __forceinline__ uint32_t row16_min(uint32_t v)
+{
+    uint32_t t;
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false); v = t < v ? t : v;   // quad_perm [1,0,3,2]
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false); v = t < v ? t : v;   // quad_perm [2,3,0,1]
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false); v = t < v ? t : v;  // row_half_mirror
+    t = (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false); v = t < v ? t : v;  // row_mirror
+    return v;
 }
 
 // tuple(token) / word[-1] + "</w>"  (tokenize.py:63-64): code point -> initial symbol
@@ -420,24 +446,74 @@ __device__ __forceinline__ void group_flush(Group& G)
     const GzDeviceTables& T = *G.Tp;
     const int lane = G.lane;
     // ---- the misses: decode, merge, look up (one lane per word) ---------------------------------------------------
-    if (lane < G.nmiss && (G.ablate & 2)) L.miss_ntok[lane] = 1;
-    if (lane < G.nmiss && !(G.ablate & 2)) {
-        const uint8_t* g = G.base + G.B0 + L.miss_off[lane];
-        const int nb = L.miss_len[lane] & 0x7FFF;
-        const bool glue = (L.miss_len[lane] >> 15) != 0;
-        auto at = [&](int64_t i) -> uint32_t { return g[i]; };
-        int n = 0, i = 0;
-        while (i < nb) {
-            int len;
-            const uint32_t cp = decode_cp(at, i, nb, len);
-            L.sym[n * WAVE + lane] = initial_symbol(T, cp, !glue && i + len >= nb);
-            ++n;
-            i += len;
+    // Sixteen lanes (one DPP row) per word, four words per pass: every adjacent pair of a word is probed in the same
+    // instruction, the row minimum picks the pair to merge (tokenize.py:70-73), every occurrence merges left to
+    // right (:75-92) and the row is compacted through LDS.  One dependent table load per merge iteration.
+    if (G.ablate & 2) { if (lane < G.nmiss) L.miss_ntok[lane] = 1; }
+    else for (int c0 = 0; c0 < G.nmiss; c0 += 4) {
+        const int row = lane >> 4, k = lane & 15;
+        const int m = c0 + row;
+        const bool mv = m < G.nmiss;
+        const uint8_t* g = G.base + G.B0 + (mv ? L.miss_off[m] : 0u);
+        const int nb = mv ? (L.miss_len[m] & 0x7FFF) : 0;
+        const bool glue = mv && (L.miss_len[m] >> 15) != 0;
+        uint32_t* S = L.sym + 16 * m;                       // this word's symbols
+        // -- initial symbols: lane k looks at bytes k, k+16, k+32, k+48 of its word
+        int ncp = 0;
+        uint32_t leadbits[4];
+        uint32_t bytev[4];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int b = 16 * p + k;
+            bytev[p] = b < nb ? g[b] : 0x80u;
+            const uint64_t bal = __ballot(b < nb && (bytev[p] & 0xC0u) != 0x80u);
+            leadbits[p] = (uint32_t)(bal >> (16 * row)) & 0xFFFFu;
+            ncp += __popc(leadbits[p]);
         }
-        if (glue) { L.sym[n * WAVE + lane] = initial_symbol(T, 0x0Au, true); ++n; }
-        if (!(G.ablate & 1)) n = lane_merge(T, L, lane, n);
-        for (int k = 0; k < n; ++k) L.sym[k * WAVE + lane] = (uint32_t)token_id(T, L.sym[k * WAVE + lane], k == n - 1);
-        L.miss_ntok[lane] = (uint8_t)n;
+        int n = ncp + (glue ? 1 : 0);
+        int before = 0;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const int b = 16 * p + k;
+            if (b < nb && (bytev[p] & 0xC0u) != 0x80u) {
+                auto at = [&](int64_t i) -> uint32_t { return g[i]; };
+                int len;
+                const uint32_t cp = decode_cp(at, b, nb, len);
+                const int idx = before + __popc(leadbits[p] & ((1u << k) - 1u));
+                S[idx] = initial_symbol(T, cp, !glue && idx == ncp - 1);
+            }
+            before += __popc(leadbits[p]);
+        }
+        if (mv && glue && k == 0) S[n - 1] = initial_symbol(T, 0x0Au, true);
+        // -- merge iterations
+        if (!(G.ablate & 1)) for (;;) {
+            const uint32_t s = (mv && k < n) ? S[k] : GZ_NO_SYMBOL;
+            const uint32_t s1 = (mv && k + 1 < n) ? S[k + 1] : GZ_NO_SYMBOL;
+            uint32_t merged = 0;
+            const uint32_t rank = (mv && k + 1 < n) ? probe_pair(T, s, s1, merged) : GZ_RANK_NONE;
+            const uint32_t best = row16_min(rank);
+            const uint64_t M = __ballot(best != GZ_RANK_NONE && rank == best);
+            if (M == 0) break;                                  // no row has a ranked pair left
+            uint64_t pick = M;
+            if (M & (M << 1)) {                                 // overlapping occurrences (first == second): greedy
+                pick = 0;
+                uint64_t rem = M;
+                while (rem) {
+                    const uint64_t low = rem & (0 - rem);
+                    pick |= low;
+                    rem &= ~(low | (low << 1));
+                }
+            }
+            const bool picked = (pick >> lane) & 1ull;
+            const bool consumed = lane > 0 && ((pick >> (lane - 1)) & 1ull);
+            const bool keep = mv && k < n && !consumed;
+            const uint32_t keep16 = (uint32_t)(__ballot(keep) >> (16 * row)) & 0xFFFFu;
+            if (keep) S[__popc(keep16 & ((1u << k) - 1u))] = picked ? merged : s;
+            n -= __popc((uint32_t)(pick >> (16 * row)) & 0xFFFFu);
+        }
+        // -- ids
+        if (mv && k < n) S[k] = (uint32_t)token_id(T, S[k], k == n - 1);
+        if (mv && k == 0) L.miss_ntok[m] = (uint8_t)n;
     }
     // ---- positions: segmented exclusive prefix sum of the token counts, one segment per document -----------------
     for (int c0 = 0; c0 < G.nrec; c0 += WAVE) {
@@ -460,7 +536,7 @@ __device__ __forceinline__ void group_flush(Group& G)
         if (valid) {
             const int pos = L.doc_ntok[doc] + seg_excl;
             if (!miss) group_emit(G, doc, pos, (int32_t)payload);
-            else for (int k = 0; k < cnt; ++k) group_emit(G, doc, pos + k, (int32_t)L.sym[k * WAVE + payload]);
+            else for (int k = 0; k < cnt; ++k) group_emit(G, doc, pos + k, (int32_t)L.sym[16 * payload + k]);
             if (tail) L.doc_ntok[doc] = pos + cnt;
         }
     }
@@ -515,18 +591,26 @@ __device__ __forceinline__ bool group_text(Group& G)
     while (pos < G.B1) {
         uint32_t st16, en16;
         group_tile(G, pos, true, st16, en16);
-        int n_starts, n_ends;
+        int n_starts;
         int sidx = wave_excl_sum(__popc(st16), lane, n_starts);
-        int eidx = wave_excl_sum(__popc(en16), lane, n_ends);
         for (uint32_t m = st16; m; m &= m - 1) L.wstart[sidx++] = (uint16_t)(16 * lane + __ffs(m) - 1);
-        for (uint32_t m = en16; m; m &= m - 1) L.wend[eidx++] = (uint16_t)(16 * lane + __ffs(m) - 1);
+        reinterpret_cast<uint16_t*>(L.endmap)[lane] = (uint16_t)en16;
         const uint32_t tile_rel = (uint32_t)(pos - G.B0);
-        const int nw = n_ends;                                  // complete words of this tile
+        // the last word of the tile is cut when no word end follows its start
+        const uint64_t endlanes = __ballot(en16 != 0);
+        int e_last = -1;
+        if (endlanes) {
+            const int hl = 63 - __clzll((long long)endlanes);
+            e_last = 16 * hl + 31 - __clz((int)__shfl((int)en16, hl, WAVE));
+        }
+        const int s_last = n_starts > 0 ? (int)L.wstart[n_starts - 1] : -1;
+        const bool cut_word = n_starts > 0 && e_last <= s_last;
+        const int nw = cut_word ? n_starts - 1 : n_starts;      // complete words of this tile
 
         // a word that fills the whole tile: find its end by scanning forward, then treat it as one long word
         int64_t giant_len = -1;
         bool giant_glue = false;
-        if (n_starts > n_ends && nw == 0 && L.wstart[0] == 0) {
+        if (cut_word && nw == 0 && s_last == 0) {
             int64_t q = pos + TILE;
             int64_t wend_abs = G.B1;
             bool at_break = false;
@@ -554,7 +638,13 @@ __device__ __forceinline__ bool group_text(Group& G)
             const int wi = rd * WAVE + lane;
             bool have = giant_len < 0 && wi < nw;
             const int ws = have ? L.wstart[wi] : 0;
-            const int we = have ? L.wend[wi] : 0;
+            int we = 0;
+            if (have) {                                             // first word end after the start
+                int q = (ws + 1) >> 5;
+                uint32_t bits = L.endmap[q] & (~0u << ((ws + 1) & 31));
+                while (bits == 0) bits = L.endmap[++q];
+                we = 32 * q + __ffs(bits) - 1;
+            }
             const bool glue = have && lds_bytes[we] == 0x0Au && !((L.brk[we >> 5] >> (we & 31)) & 1u);   // "\S+\n?"
             const int nb = we - ws;
             const uint32_t a_rel = tile_rel + (uint32_t)ws;
@@ -564,7 +654,7 @@ __device__ __forceinline__ bool group_text(Group& G)
             if (have && nb + (glue ? 1 : 0) > MAXSYM) {
                 int leads = glue ? 1 : 0;
                 for (int i = ws; i < we; ++i) leads += (lds_bytes[i] & 0xC0u) != 0x80u;
-                is_long = leads > MAXSYM;
+                is_long = leads > MAXSYM || nb > 4 * MAXSYM;
             }
             // whole-word table: a plain word of <= 16 bytes whose bpe() is known to be ONE piece needs no merge loop
             bool hit = false;
@@ -636,7 +726,7 @@ __device__ __forceinline__ bool group_text(Group& G)
         }
 
         if (giant_len >= 0) pos += giant_len + (giant_glue ? 1 : 0);
-        else if (n_starts > n_ends) pos += L.wstart[n_ends];        // re-tile at the start of the cut word (> 0 here)
+        else if (cut_word) pos += s_last;                           // re-tile at the start of the cut word (> 0 here)
         else pos += TILE;
     }
     return true;
@@ -647,7 +737,7 @@ __device__ __forceinline__ bool group_text(Group& G)
 // =================================================================================================================
 // gz_encode_kernel
 // =================================================================================================================
-__global__ __launch_bounds__(WAVE * WPB) void gz_encode_kernel(const GzDeviceTables* __restrict__ Tp, GzEncodeArgs A)
+__global__ __launch_bounds__(WAVE * WPB) __attribute__((amdgpu_waves_per_eu(4, 4))) void gz_encode_kernel(const GzDeviceTables* __restrict__ Tp, GzEncodeArgs A)
 {
     __shared__ WaveLds lds[WPB];
     const GzDeviceTables& T = *Tp;

@@ -6,7 +6,7 @@
 //
 //   symbols   every string bpe() can hold in its `word` tuple: merge operands, merge results, and the
 //             single-character forms the vocab knows (c  and  c+"</w>").  Interned by string identity.
-//   pair_tab  open-addressing hash  (left symbol, right symbol) -> rank          [bpe_ranks.get(pair)]
+//   pair_tab  open-addressing hash  (left symbol, right symbol) -> rank, merged symbol   [bpe_ranks.get(pair)]
 //   merges    rank -> (left, right, merged symbol)                              [first + second, tokenize.py:88]
 //   sym_ids   symbol -> vocab id when emitted as a non-final piece (string + "@@") and as the final piece
 //             (string minus "</w>")                                              [encoder.get(tok, unk), :120-121]
@@ -302,13 +302,13 @@ int gz_build_tables(const uint8_t* vocab, size_t vocab_len, const uint8_t* bpe, 
     {
         size_t slots = 16;
         while (slots < 2 * pairs.size()) slots <<= 1;
-        T.pair_tab.assign(slots, GZ_PAIR_EMPTY);
+        T.pair_tab.assign(slots, GzPairSlot{GZ_PAIR_EMPTY, 0, 0});
         uint32_t worst = 0;
         for (const Pair& p : pairs) {
             size_t h = gz_pair_hash(p.a, p.b) & (slots - 1);
             uint32_t probes = 1;
-            while (T.pair_tab[h] != GZ_PAIR_EMPTY) { h = (h + 1) & (slots - 1); ++probes; }
-            T.pair_tab[h] = gz_pair_entry(p.a, p.b, p.rank);
+            while (T.pair_tab[h].keyrank != GZ_PAIR_EMPTY) { h = (h + 1) & (slots - 1); ++probes; }
+            T.pair_tab[h] = GzPairSlot{gz_pair_entry(p.a, p.b, p.rank), T.merges[p.rank].merged, 0};
             worst = std::max(worst, probes);
         }
         T.max_probe = worst;

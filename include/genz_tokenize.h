@@ -139,7 +139,7 @@ int  gz_memcpy_d2h(gz_ctx *ctx, void *dst_host, const void *src_device, size_t b
 int  gz_timing(gz_ctx *ctx, double out_ms[4]);
 
 /* Offline / diagnostic table build on the HOST only (no GPU needed): the same builder gz_load_tables runs, with
- * the integer tables it would upload exposed read-only.  `which`: 0 pair hash (uint64 [slots]), 1 merges
+ * the integer tables it would upload exposed read-only.  `which`: 0 pair hash (uint64 x2 [slots]: key<<24|rank, merged symbol), 1 merges
  * (uint32 x4 [n_lines]: left,right,merged,0), 2 symbol ids (int32 x2 [n_symbols]: non-final, final), 3 BMP code
  * point table (uint32 x2 [65536]: plain, final), 4 astral table (uint32 x4 [slots]: cp,plain,final,0; may be
  * empty), 5 special ids (int32 [5]).  Pointers stay valid until gz_host_tables_destroy. */

@@ -26,7 +26,9 @@ def cp_hash(cp):
 
 class TableSim:
     def __init__(self, H):
-        self.pair = [int(x) for x in H.array(0)]
+        pt = H.array(0)
+        self.pair = [int(x) for x in pt[:, 0]]
+        self.pair_merged = [int(x) & 0xFFFFFFFF for x in pt[:, 1]]
         self.mask = len(self.pair) - 1
         self.merges = H.array(1)
         self.sym_ids = H.array(2)
@@ -42,6 +44,7 @@ class TableSim:
         while True:
             e = self.pair[h]
             if (e >> 24) == key:
+                assert self.pair_merged[h] == int(self.merges[e & 0xFFFFFF][2])
                 return e & 0xFFFFFF
             if e == 0xFFFFFFFFFFFFFFFF:
                 return None
