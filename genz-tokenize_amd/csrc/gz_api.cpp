@@ -93,6 +93,7 @@ struct gz_ctx {
 
     DBuf t_words;
     int64_t n_words = 0;
+    bool building_words = false;         // the whole-word table is being built: ignore diagnostics
     bool no_words_env = false;           // GZ_WORD_TABLE=0 in the environment
     const int64_t* hint_off = nullptr;   // last device offsets array whose byte total was read back
     int64_t hint_n = -1, hint_bytes = 0;
@@ -253,7 +254,7 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
     }
     {
         const int64_t avg = n_docs > 0 ? text_bytes / n_docs : 0;
-        int64_t dpw = avg > 0 ? 2048 / avg : GZ_MAX_DOCS_PER_WAVE;
+        int64_t dpw = avg > 0 ? 4096 / avg : GZ_MAX_DOCS_PER_WAVE;
         const int64_t by_waves = n_docs / 16384;                 // keep >= 16 K waves when the batch allows it
         if (dpw > by_waves) dpw = by_waves;
         if (dpw < 1) dpw = 1;
@@ -261,7 +262,7 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
         A.docs_per_wave = (int32_t)dpw;
         if (const char* e = getenv("GZ_DOCS_PER_WAVE")) { int v = atoi(e); if (v >= 1 && v <= GZ_MAX_DOCS_PER_WAVE) A.docs_per_wave = v; }
         const char* ab = getenv("GZ_ABLATE");       // timing diagnostics only: results are wrong when set
-        A.ablate = ab ? atoi(ab) : 0;
+        A.ablate = (ab && !c->building_words) ? atoi(ab) : 0;
     }
     if (!dense) {
         if (raw_elems < 0) {
@@ -330,8 +331,10 @@ static int build_word_table(gz_ctx* c)
     const int64_t cap = (int64_t)text.size() + 2 * n;
     std::vector<int32_t> ids((size_t)cap), mask((size_t)cap), nreal((size_t)n);
     std::vector<int64_t> row((size_t)n + 1);
+    c->building_words = true;
     int rc = encode_host_locked(c, text.data(), off.data(), nullptr, nullptr, n, 0, GZ_MAX_LEN_NONE | GZ_NO_WORD_TABLE, cap,
                                 ids.data(), mask.data(), nullptr, nullptr, row.data(), nullptr, nreal.data(), nullptr);
+    c->building_words = false;
     if (rc) return rc;
     std::vector<GzWordSlot> found;
     for (int64_t i = 0; i < n; ++i) {

@@ -516,7 +516,7 @@ __device__ __forceinline__ void group_flush(Group& G)
         if (mv && k == 0) L.miss_ntok[m] = (uint8_t)n;
     }
     // ---- positions: segmented exclusive prefix sum of the token counts, one segment per document -----------------
-    for (int c0 = 0; c0 < G.nrec; c0 += WAVE) {
+    if (!(G.ablate & 32)) for (int c0 = 0; c0 < G.nrec; c0 += WAVE) {
         const int r = c0 + lane;
         const bool valid = r < G.nrec;
         const uint32_t rec = valid ? L.rec[r] : 0u;
@@ -591,6 +591,8 @@ __device__ __forceinline__ bool group_text(Group& G)
     while (pos < G.B1) {
         uint32_t st16, en16;
         group_tile(G, pos, true, st16, en16);
+        if (G.ablate & 16) { st16 = 0; en16 = 0; }
+        if (G.ablate & 128) { st16 = (pos + 16 * lane < G.B1) ? 0x1111u : 0; en16 = st16 << 2; }   // fake words, no classify
         int n_starts;
         int sidx = wave_excl_sum(__popc(st16), lane, n_starts);
         for (uint32_t m = st16; m; m &= m - 1) L.wstart[sidx++] = (uint16_t)(16 * lane + __ffs(m) - 1);
@@ -659,7 +661,8 @@ __device__ __forceinline__ bool group_text(Group& G)
             // whole-word table: a plain word of <= 16 bytes whose bpe() is known to be ONE piece needs no merge loop
             bool hit = false;
             uint32_t hit_id = 0;
-            if (G.words != nullptr && have && !glue && nb <= 16) {
+            if (G.ablate & 64) { hit = have; hit_id = 7; }
+            else if (G.words != nullptr && have && !glue && nb <= 16) {
                 const uint64_t* q = reinterpret_cast<const uint64_t*>(L.bytes) + (ws >> 3);
                 const uint64_t x0 = q[0], x1 = q[1], x2 = q[2];
                 const int sh = (ws & 7) * 8;
