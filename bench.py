@@ -143,6 +143,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- secondary measurement (untimed for `value`): the same step with the whole-word table switched off, i.e.
+    # every word through the merge loop
+    merge_only = None
+    if world == 1:
+        fl2 = flags | _native.GZ_NO_WORD_TABLE
+        ms2 = []
+        for _ in range(1 + min(args.steps, 5)):
+            ctx.encode_device(d_text, d_off, 0, 0, n, L, fl2, n * L, d_ids, d_mask, d_n_real=d_nreal)
+            ctx.sync()
+            ms2.append(ctx.timing()[0])
+        k2 = float(np.mean(ms2[1:]))
+        merge_only = {"kernel_ms_avg": round(k2, 4), "MB_per_s_kernel": round(in_bytes / k2 / 1e3, 1)}
+        # leave the buffers holding the table-on result for the verification below
+        ctx.encode_device(d_text, d_off, 0, 0, n, L, flags, n * L, d_ids, d_mask, d_n_real=d_nreal)
+        ctx.sync()
+
     # ---- after the timed region: counts, verification, CPU baseline -------------------------------------------------
     n_real = np.empty(n, dtype=np.int32); ctx.d2h(n_real, d_nreal)
     tokens_local = int(n_real.sum())
@@ -209,6 +225,7 @@ def main():
                          "traffic": None, "algorithmic_bytes_per_launch": algo,
                          "kernel_ms_avg": round(k_ms, 4), "timed_with": "hipEvents on the library's stream"},
             "verified": verify,
+            "merge_loop_only": merge_only,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(text, offs, L)

@@ -1,0 +1,71 @@
+"""world_size-2 `gloo` coverage of the multi-GPU model on CPU: shard planning and the gatherv
+contract of `gz_gather_rows`, with rows produced by the oracle standing in for the per-rank GPU work."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
+
+
+def test_plan_shards_balanced_and_ordered():
+    from genz_tokenize.distributed import plan_shards
+    rng = np.random.default_rng(0)
+    sizes = rng.integers(0, 3000, size=10_000)
+    offs = np.concatenate([[7], 7 + np.cumsum(sizes)]).astype(np.int64)
+    for world in (1, 2, 3, 8):
+        sh = plan_shards(offs, world)
+        assert sh[0][0] == 0 and sh[-1][1] == 10_000
+        assert all(a[1] == b[0] for a, b in zip(sh, sh[1:]))
+        b = [int(offs[hi] - offs[lo]) for lo, hi in sh]
+        assert max(b) - min(b) <= 2 * 3000
+    # degenerate inputs
+    assert plan_shards(np.array([0, 0, 0, 0], dtype=np.int64), 2) == [(0, 0), (0, 3)] or \
+        sum(hi - lo for lo, hi in plan_shards(np.array([0, 0, 0, 0], dtype=np.int64), 2)) == 3
+    assert plan_shards(np.array([0], dtype=np.int64), 4) == [(0, 0)] * 4
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle")); sys.path.insert(0, os.path.join(ROOT, "genz-tokenize_amd"))
+    import torch.distributed as dist
+    import corpus
+    import gz_oracle as O
+    from genz_tokenize.distributed import GlooTransport, plan_shards
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
+    try:
+        t = O.Tables(open(corpus.VOCAB_PATH, "rb").read(), open(corpus.BPE_PATH, "rb").read())
+        text, offs, _ = corpus.config_corpus(2, n_docs=301, seed=9)
+        L = 24
+        lo, hi = plan_shards(offs, world)[rank]
+        raw = text.tobytes()
+        rows = np.array([O.call(t, raw[offs[i]:offs[i + 1]].decode(), max_len=L)["input_ids"] for i in range(lo, hi)],
+                        dtype=np.int32).reshape(-1, L)
+        rpr = [h - l for l, h in plan_shards(offs, world)]
+        got = GlooTransport(rank, world).gather_rows(rows, rpr, L, root=0)
+        if rank == 0:
+            want = np.array([O.call(t, raw[offs[i]:offs[i + 1]].decode(), max_len=L)["input_ids"] for i in range(301)],
+                            dtype=np.int32)
+            q.put(bool(np.array_equal(got, want)))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_gather_rows_world2_gloo():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    assert q.get(timeout=5) is True
