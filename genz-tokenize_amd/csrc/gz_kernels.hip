@@ -46,6 +46,14 @@ struct alignas(16) WaveLds {
 };
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
+
+// streaming (write-once) 16-byte store that does not displace the tables from L2
+__device__ __forceinline__ void nt_store4(int32_t* p, int32_t a, int32_t b, int32_t c, int32_t d)
+{
+    typedef int __attribute__((ext_vector_type(4))) v4i;
+    v4i v = {a, b, c, d};
+    __builtin_nontemporal_store(v, reinterpret_cast<v4i*>(p));
+}
 __device__ __forceinline__ uint64_t lt_mask(int lane) { return (1ull << lane) - 1ull; }
 
 __device__ __forceinline__ int wave_excl_sum(int v, int lane, int& total)
@@ -284,24 +292,68 @@ __device__ __noinline__ int long_word(const GzDeviceTables* Tp, WaveLds& L, cons
 // continuation bytes (tail of a whitespace code point cut by the previous tile) count as whitespace too.
 // `brk16`: bit j set = a document starts at byte 16*lane+j.
 // ---------------------------------------------------------------------------------------------------------------
+// SWAR helpers on 4 packed bytes: results have bit 7 of a byte set where the predicate holds
+__device__ __forceinline__ uint32_t swar_eq(uint32_t x, uint32_t c)
+{
+    const uint32_t t = x ^ (c * 0x01010101u);
+    return ~(((t & 0x7F7F7F7Fu) + 0x7F7F7F7Fu) | t) & 0x80808080u;
+}
+__device__ __forceinline__ uint32_t swar_ge7(uint32_t x7o, uint32_t c)      // x7o = (x & 0x7F..) | 0x80..;  low 7 bits >= c
+{
+    return (x7o - c * 0x01010101u) & 0x80808080u;
+}
+__device__ __forceinline__ uint32_t swar_bits(uint32_t m0, uint32_t m1, uint32_t m2, uint32_t m3)   // MSB masks -> 16 bits
+{
+    const uint32_t n0 = ((m0 >> 7) * 0x00204081u) >> 21 & 0xFu, n1 = ((m1 >> 7) * 0x00204081u) >> 21 & 0xFu;
+    const uint32_t n2 = ((m2 >> 7) * 0x00204081u) >> 21 & 0xFu, n3 = ((m3 >> 7) * 0x00204081u) >> 21 & 0xFu;
+    return n0 | (n1 << 4) | (n2 << 8) | (n3 << 12);
+}
+
 __device__ __forceinline__ void classify(const uint32_t w[4], uint32_t w4, int lane, bool prev_ws0, uint32_t brk16,
                                          uint32_t& start16, uint32_t& end16)
 {
-    uint32_t lead = 0, ws = 0, ws23 = 0, ws3 = 0;
+    uint32_t leadm[4], wsm[4], ws23m[4], c3m[4];
+    uint32_t any3 = 0;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) {
-        auto byte = [&](int k) -> uint32_t { return k < 16 ? (w[k >> 2] >> ((k & 3) * 8)) & 0xFFu : (w4 >> ((k - 16) * 8)) & 0xFFu; };
-        const uint32_t b = byte(j), n1 = byte(j + 1), n2 = byte(j + 2);
-        const bool is_lead = (b & 0xC0u) != 0x80u;
-        const bool a1 = b == 0x20u || (b >= 0x09u && b <= 0x0Du) || (b >= 0x1Cu && b <= 0x1Fu);
-        const bool a2 = b == 0xC2u && (n1 == 0x85u || n1 == 0xA0u);
-        const bool a3 = (b == 0xE2u && ((n1 == 0x80u && ((n2 >= 0x80u && n2 <= 0x8Au) || n2 == 0xA8u || n2 == 0xA9u || n2 == 0xAFu)) ||
-                                        (n1 == 0x81u && n2 == 0x9Fu))) ||
-                        (b == 0xE1u && n1 == 0x9Au && n2 == 0x80u) || (b == 0xE3u && n1 == 0x80u && n2 == 0x80u);
-        lead |= (uint32_t)is_lead << j;
-        ws |= (uint32_t)(a1 || a2 || a3) << j;
-        ws23 |= (uint32_t)(a2 || a3) << j;
-        ws3 |= (uint32_t)a3 << j;
+    for (int i = 0; i < 4; ++i) {
+        const uint32_t x = w[i], nx = i < 3 ? w[i + 1] : w4;
+        const uint32_t y = (x >> 8) | (nx << 24);                         // the following byte, aligned
+        const uint32_t hi = x & 0x80808080u, x7o = x | 0x80808080u;
+        leadm[i] = ~(x & ~(x << 1)) & 0x80808080u;                        // not 10xxxxxx
+        // ASCII whitespace: 09..0D, 1C..20
+        const uint32_t a1 = ((swar_ge7(x7o, 0x09u) & ~swar_ge7(x7o, 0x0Eu)) | (swar_ge7(x7o, 0x1Cu) & ~swar_ge7(x7o, 0x21u))) & ~hi;
+        // C2 85 / C2 A0
+        const uint32_t a2 = swar_eq(x, 0xC2u) & (swar_eq(y, 0x85u) | swar_eq(y, 0xA0u));
+        // candidates for the 3-byte ones: E1 9A .. / E2 80|81 .. / E3 80 ..
+        const uint32_t eE = swar_ge7(x7o, 0x61u) & ~swar_ge7(x7o, 0x64u) & hi;   // E1..E3
+        const uint32_t b0 = (x << 7) & 0x80808080u, b1 = (x << 6) & 0x80808080u;
+        const uint32_t y80 = swar_eq(y, 0x80u);
+        const uint32_t c3 = eE & ((b0 & ~b1 & swar_eq(y, 0x9Au)) | (~b0 & b1 & (y80 | swar_eq(y, 0x81u))) | (b0 & b1 & y80));
+        wsm[i] = a1 | a2;
+        ws23m[i] = a2;
+        c3m[i] = c3;
+        any3 |= c3;
+    }
+    uint32_t lead = swar_bits(leadm[0], leadm[1], leadm[2], leadm[3]);
+    uint32_t ws = swar_bits(wsm[0], wsm[1], wsm[2], wsm[3]);
+    uint32_t ws23 = swar_bits(ws23m[0], ws23m[1], ws23m[2], ws23m[3]);
+    uint32_t ws3 = 0;
+    if (__ballot(any3 != 0)) {                                           // rare: look at the third byte
+        uint32_t c = swar_bits(c3m[0], c3m[1], c3m[2], c3m[3]);
+        for (; c; c &= c - 1) {
+            const int j = __ffs(c) - 1;
+            auto byte = [&](int k) -> uint32_t {
+                const uint32_t ww = k < 4 ? w[0] : k < 8 ? w[1] : k < 12 ? w[2] : k < 16 ? w[3] : w4;
+                return (ww >> ((k & 3) * 8)) & 0xFFu;
+            };
+            const uint32_t b = byte(j), n1 = byte(j + 1), n2 = byte(j + 2);
+            const bool a3 = (b == 0xE2u && ((n1 == 0x80u && ((n2 >= 0x80u && n2 <= 0x8Au) || n2 == 0xA8u || n2 == 0xA9u || n2 == 0xAFu)) ||
+                                            (n1 == 0x81u && n2 == 0x9Fu))) ||
+                            (b == 0xE1u && n1 == 0x9Au && n2 == 0x80u) || (b == 0xE3u && n1 == 0x80u && n2 == 0x80u);
+            ws3 |= (uint32_t)a3 << j;
+        }
+        ws |= ws3;
+        ws23 |= ws3;
     }
     uint32_t full = ws | (ws23 << 1) | (ws3 << 2);           // every byte of a whitespace code point (18 bits)
     uint32_t carry = (uint32_t)__shfl_up((int)(full >> 16), 1, WAVE);
@@ -333,7 +385,8 @@ __device__ __forceinline__ void load_tile(const uint8_t* base, int64_t pos, int6
     uint32_t r[4] = {0x20202020u, 0x20202020u, 0x20202020u, 0x20202020u};
     if (nv > 0) {
         if (g + 16 <= buf_end) {
-            const uint4 v = *reinterpret_cast<const uint4_u*>(base + g);
+            typedef unsigned __attribute__((ext_vector_type(4), aligned(1))) v4u_u;
+            const auto v = __builtin_nontemporal_load(reinterpret_cast<const v4u_u*>(base + g));
             r[0] = v.x; r[1] = v.y; r[2] = v.z; r[3] = v.w;
         } else {
             for (int k = 0; k < (int)nv; ++k) {
@@ -819,9 +872,9 @@ __global__ __launch_bounds__(WAVE * WPB) __attribute__((amdgpu_waves_per_eu(4, 4
         if ((Lm & 3) == 0) {
             for (int c = lane; c < Lm / 4; c += WAVE) {
                 const int i0 = 4 * c;
-                if (i0 >= first) *reinterpret_cast<int4*>(ids + i0) = make_int4(tailv, tailv, tailv, tailv);
+                if (i0 >= first) nt_store4(ids + i0, tailv, tailv, tailv, tailv);
                 else if (i0 + 4 > first) for (int i = first; i < i0 + 4; ++i) ids[i] = tailv;
-                if (!slow) *reinterpret_cast<int4*>(mask + i0) = make_int4(i0 < t, i0 + 1 < t, i0 + 2 < t, i0 + 3 < t);
+                if (!slow) nt_store4(mask + i0, i0 < t, i0 + 1 < t, i0 + 2 < t, i0 + 3 < t);
             }
         } else {
             for (int i = lane; i < Lm; i += WAVE) {
