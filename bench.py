@@ -32,6 +32,10 @@ for p in (ROOT, os.path.join(ROOT, "genz-tokenize_amd"), os.path.join(ROOT, "ora
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
+# HBM bytes per launch of gz_encode_kernel on the default workload, from the PMC passes kept in
+# profiles/r01_v2_pmc_traffic.txt: (FETCH_SIZE 1 468 443 KiB + WRITE_SIZE 3 265 434 KiB) * 1024 (separate --pmc runs;
+# read side not corrected for the gfx950 half-count of wide streaming reads: at most +0.14 GB)
+MEASURED_TRAFFIC_DEFAULT_WORKLOAD = (1468443 + 3265434) * 1024
 
 
 def cpu_baseline(text, offs, max_len, budget_s=12.0):
@@ -69,6 +73,7 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="(diagnostic) skip the RCCL gather at N > 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
+    ap.add_argument("--no-merge-only", action="store_true", help="skip the secondary run without the whole-word table")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -146,7 +151,7 @@ def main():
     # ---- secondary measurement (untimed for `value`): the same step with the whole-word table switched off, i.e.
     # every word through the merge loop
     merge_only = None
-    if world == 1:
+    if world == 1 and not args.no_merge_only:
         fl2 = flags | _native.GZ_NO_WORD_TABLE
         ms2 = []
         for _ in range(1 + min(args.steps, 5)):
@@ -222,7 +227,9 @@ def main():
                        "inputs": "resident in HBM before the timed region"},
             "roofline": {"bound": "hbm", "kernel": "gz_encode_kernel", "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": None, "algorithmic_bytes_per_launch": algo,
+                         "traffic": MEASURED_TRAFFIC_DEFAULT_WORKLOAD if (n == 1_000_000 and L == 256) else None,
+                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01_v2_pmc_traffic.txt",
+                         "algorithmic_bytes_per_launch": algo,
                          "kernel_ms_avg": round(k_ms, 4), "timed_with": "hipEvents on the library's stream"},
             "verified": verify,
             "merge_loop_only": merge_only,

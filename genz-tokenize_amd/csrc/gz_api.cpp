@@ -263,6 +263,7 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
         if (const char* e = getenv("GZ_DOCS_PER_WAVE")) { int v = atoi(e); if (v >= 1 && v <= GZ_MAX_DOCS_PER_WAVE) A.docs_per_wave = v; }
         const char* ab = getenv("GZ_ABLATE");       // timing diagnostics only: results are wrong when set
         A.ablate = (ab && !c->building_words) ? atoi(ab) : 0;
+        A.table_build = c->building_words ? 1 : 0;
     }
     if (!dense) {
         if (raw_elems < 0) {

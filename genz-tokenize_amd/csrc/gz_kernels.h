@@ -30,6 +30,7 @@ struct GzEncodeArgs {
     int32_t huge_pass;    // 1: only groups whose first document has n_real == GZ_DEFERRED
     int32_t docs_per_wave; // 1 .. GZ_MAX_DOCS_PER_WAVE (chosen by the host from the average document size)
     int32_t use_words;     // consult the whole-word table (GzDeviceTables::words)
+    int32_t table_build;   // launched by the whole-word table build (separate kernel name for profiles)
     int32_t ablate;        // timing diagnostics only (env GZ_ABLATE; results are WRONG when non-zero): 1 no merge loop,
                            // 2 no miss decode/merge at all, 4 no token stores, 8 no pad/mask fill, 16 no tile classify
 };
