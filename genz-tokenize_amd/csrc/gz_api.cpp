@@ -84,6 +84,9 @@ struct gz_ctx {
         bool pair = false;
         GzPairArgs P{};
         bool timing = false;
+        bool pipeline = false;
+        GzAsmArgs S{};
+        int use_words = 0;
     } pend;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     double timing[4] = {0, 0, 0, 0};
@@ -92,6 +95,8 @@ struct gz_ctx {
     int rank = 0, world = 1;
 
     DBuf t_words;
+    struct TextWs { DBuf brk, st, en, blkcnt, docw0, wtok, waux, mtok; } tw[2];
+    bool use_pipeline = true;            // GZ_PIPELINE=0 selects the fused single-kernel path
     int64_t n_words = 0;
     bool building_words = false;         // the whole-word table is being built: ignore diagnostics
     bool no_words_env = false;           // GZ_WORD_TABLE=0 in the environment
@@ -162,7 +167,13 @@ int enqueue(gz_ctx* c, bool huge_pass)
     p.A.arena = huge_pass ? (uint32_t*)c->w_arena.p : nullptr;
     HIPCHK(c, hipMemsetAsync(c->w_flags.p, 0, 8, s));      // [0] defer, [1] capacity error
     if (p.timing) HIPCHK(c, hipEventRecord(c->ev[0], s));
-    gz_launch_encode((const GzDeviceTables*)c->t_struct.p, p.A, s);
+    if (p.pipeline) {
+        for (int tx = 0; tx < p.S.n_texts; ++tx)
+            gz_launch_pipeline_text((const GzDeviceTables*)c->t_struct.p, p.S.X[tx], p.S.n_docs, p.use_words, s);
+        gz_launch_assemble((const GzDeviceTables*)c->t_struct.p, p.S, s);
+    } else {
+        gz_launch_encode((const GzDeviceTables*)c->t_struct.p, p.A, s);
+    }
     if (p.timing) HIPCHK(c, hipEventRecord(c->ev[1], s));
     if (p.ragged) {
         gz_launch_rowscan(p.F, (int64_t*)c->w_rowlen.p, s);
@@ -214,7 +225,8 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
                          int32_t* input_ids, int32_t* attention_mask, int32_t* token_type_ids, int32_t* sequence_id,
                          int64_t* row_off, int32_t* pair_len, int32_t* n_real, int32_t* status,
                          int64_t raw_elems /* < 0: unknown, read offsets from the device */,
-                         int64_t text_bytes /* < 0: unknown */)
+                         int64_t text_bytes /* < 0: unknown */, int64_t pair_bytes = -1, int64_t text_beg = 0,
+                         int64_t pair_beg = 0)
 {
     if (!c->have_tables) return fail(c, GZ_E_NOTABLES, "gz_load_tables has not been called");
     if (n_docs < 0 || !text_off || (n_docs > 0 && !text)) return fail(c, GZ_E_INVALID, "bad text arguments");
@@ -243,14 +255,17 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
     A.use_words = (c->dev.words != nullptr && !(flags & GZ_NO_WORD_TABLE) && !c->no_words_env) ? 1 : 0;
     // documents per wave: enough bytes per wave to fill its 1-KiB tiles, enough waves to fill the chip
     if (text_bytes < 0) {
-        if (c->hint_off == text_off && c->hint_n == n_docs) text_bytes = c->hint_bytes;   // speed only: a stale hint is harmless
-        else {
-            int64_t b[2] = {0, 0};
-            HIPCHK(c, hipMemcpy(&b[0], text_off, 8, hipMemcpyDeviceToHost));
-            HIPCHK(c, hipMemcpy(&b[1], text_off + n_docs, 8, hipMemcpyDeviceToHost));
-            text_bytes = b[1] - b[0];
-            c->hint_off = text_off; c->hint_n = n_docs; c->hint_bytes = text_bytes;
+        // sizes of the batch: two 8-byte reads per text (the workspace is sized from them, so no stale hint here)
+        int64_t b[4] = {0, 0, 0, 0};
+        HIPCHK(c, hipMemcpy(&b[0], text_off, 8, hipMemcpyDeviceToHost));
+        HIPCHK(c, hipMemcpy(&b[1], text_off + n_docs, 8, hipMemcpyDeviceToHost));
+        if (is_pair) {
+            HIPCHK(c, hipMemcpy(&b[2], pair_off, 8, hipMemcpyDeviceToHost));
+            HIPCHK(c, hipMemcpy(&b[3], pair_off + n_docs, 8, hipMemcpyDeviceToHost));
         }
+        text_bytes = b[1] - b[0]; text_beg = b[0];
+        pair_bytes = b[3] - b[2]; pair_beg = b[2];
+        if (text_bytes < 0 || pair_bytes < 0) return fail(c, GZ_E_INVALID, "offsets are not non-decreasing");
     }
     {
         const int64_t avg = n_docs > 0 ? text_bytes / n_docs : 0;
@@ -264,6 +279,36 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
         const char* ab = getenv("GZ_ABLATE");       // timing diagnostics only: results are wrong when set
         A.ablate = (ab && !c->building_words) ? atoi(ab) : 0;
         A.table_build = c->building_words ? 1 : 0;
+    }
+    p.pipeline = c->use_pipeline;
+    if (p.pipeline) {
+        GzAsmArgs& S2 = p.S;
+        S2.n_texts = is_pair ? 2 : 1;
+        S2.n_docs = n_docs; S2.dense = A.dense; S2.max_len = max_len;
+        S2.ids = input_ids; S2.mask = attention_mask; S2.raw = nullptr; S2.n_real = A.n_real;
+        S2.docs_per_wave = A.docs_per_wave;
+        p.use_words = A.use_words;
+        for (int tx = 0; tx < S2.n_texts; ++tx) {
+            GzTextBufs& X = S2.X[tx];
+            gz_ctx::TextWs& W = c->tw[tx];
+            const int64_t Bt = tx ? pair_bytes : text_bytes;
+            if (Bt >= (int64_t)0xFFFF0000ll) return fail(c, GZ_E_LIMIT, "a batch of 4 GiB or more of text must be split");
+            X.tb = (tx ? pair : text) + (tx ? pair_beg : text_beg);
+            X.off = tx ? pair_off : text_off;
+            X.B = Bt;
+            X.nblk = Bt / 4096 + 1;
+            const size_t bm = (size_t)((Bt + 1024) / 1024) * 128 + 64 + 4096;
+            int64_t wmax = Bt / 2 + n_docs + 2; if (wmax > Bt + 2) wmax = Bt + 2;
+            int rc2;
+            if ((rc2 = ensure(c, W.brk, bm)) || (rc2 = ensure(c, W.st, bm)) || (rc2 = ensure(c, W.en, bm)) ||
+                (rc2 = ensure(c, W.blkcnt, (size_t)(X.nblk + 2) * 4)) || (rc2 = ensure(c, W.docw0, (size_t)(n_docs + 2) * 4)) ||
+                (rc2 = ensure(c, W.wtok, (size_t)wmax * 4)) || (rc2 = ensure(c, W.waux, (size_t)wmax * 4)) ||
+                (rc2 = ensure(c, W.mtok, (size_t)(Bt + 32) * 4)))
+                return rc2;
+            X.brk = (uint16_t*)W.brk.p; X.st = (uint16_t*)W.st.p; X.en = (uint16_t*)W.en.p;
+            X.blkcnt = (uint32_t*)W.blkcnt.p; X.docw0 = (uint32_t*)W.docw0.p;
+            X.wtok = (uint32_t*)W.wtok.p; X.waux = (uint32_t*)W.waux.p; X.mtok = (int32_t*)W.mtok.p;
+        }
     }
     if (!dense) {
         if (raw_elems < 0) {
@@ -279,9 +324,11 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
         rc = ensure(c, c->w_raw, (size_t)raw_elems * 4 + 16); if (rc) return rc;
         rc = ensure(c, c->w_rowlen, (size_t)(n_docs + 1) * 8); if (rc) return rc;
         A.raw = (int32_t*)c->w_raw.p;
+        p.S.raw = A.raw;
         // raw token counts live in a private buffer: n_real is rewritten by the finalize kernel
         rc = ensure(c, c->w_status, (size_t)(n_docs + 1) * 4); if (rc) return rc;
         A.n_real = (int32_t*)c->w_status.p;
+        p.S.n_real = A.n_real;
         p.ragged = true;
         GzFinalizeArgs& F = p.F;
         F.text_off = text_off; F.pair_off = pair_off; F.n_docs = n_docs; F.S = S;
@@ -395,6 +442,7 @@ int gz_create(int device_id, gz_ctx** out)
     }
     std::memset(c->h_flags, 0, 64);
     if (const char* e = getenv("GZ_WORD_TABLE")) c->no_words_env = (e[0] == '0');
+    if (const char* e = getenv("GZ_PIPELINE")) c->use_pipeline = (e[0] != '0');
     for (auto& ev : c->ev) hipEventCreate(&ev);
     if (ensure(c, c->w_flags, 64) != GZ_OK) { g_create_err = c->err; gz_destroy(c); return GZ_E_NOMEM; }
     *out = c;
@@ -411,6 +459,8 @@ void gz_destroy(gz_ctx* c)
                     &c->w_poff, &c->w_ids, &c->w_mask, &c->w_tt, &c->w_seq, &c->w_rowoff, &c->w_rowlen, &c->w_pairlen,
                     &c->w_nreal, &c->w_status, &c->w_raw, &c->w_arena, &c->w_flags, &c->w_word, &c->w_wordout})
         release(*b);
+    for (auto& t : c->tw)
+        for (DBuf* b : {&t.brk, &t.st, &t.en, &t.blkcnt, &t.docw0, &t.wtok, &t.waux, &t.mtok}) release(*b);
     for (auto& ev : c->ev) if (ev) hipEventDestroy(ev);
     if (c->h_flags) hipHostFree(c->h_flags);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -584,7 +634,8 @@ static int encode_host_locked(gz_ctx* c, const uint8_t* text, const int64_t* tex
                               n_docs, max_len, flags, out_elems, (int32_t*)c->w_ids.p, (int32_t*)c->w_mask.p,
                               is_pair ? (int32_t*)c->w_tt.p : nullptr, is_pair ? (int32_t*)c->w_seq.p : nullptr,
                               (int64_t*)c->w_rowoff.p, is_pair ? (int32_t*)c->w_pairlen.p : nullptr,
-                              (int32_t*)c->w_nreal.p, is_pair ? (int32_t*)st2.p : nullptr, raw_elems, tb);
+                              (int32_t*)c->w_nreal.p, is_pair ? (int32_t*)st2.p : nullptr, raw_elems, tb, pb,
+                              text_off[0], is_pair ? pair_off[0] : 0);
     if (rc == GZ_OK) rc = sync_locked(c);
     if (rc) { release(st2); return rc; }
 

@@ -54,6 +54,34 @@ struct GzPairArgs {
     int32_t* seq; int32_t* tt; int32_t* pair_len; int32_t* status;
 };
 
+// ---- multi-kernel pipeline (gz_pipeline.inc) ---------------------------------------------------------------------
+struct GzTextBufs {              // one text (A or B) of a batch and its per-call workspace
+    const uint8_t* tb;           // first byte of the batch (text + off[0])
+    const int64_t* off;          // [n_docs+1] absolute offsets
+    int64_t B;                   // bytes of the batch
+    int64_t nblk;                // 4-KiB blocks covering positions 0 .. B
+    uint16_t* brk;               // bitmaps, 16 bits per 16 bytes: document starts / word starts / word ends
+    uint16_t* st;
+    uint16_t* en;
+    uint32_t* blkcnt;            // [nblk+1] words per block, then (scanned in place) index of each block's first word
+    uint32_t* docw0;             // [n_docs+1] index of each document's first word
+    uint32_t* wtok;              // [words] id, or MISS | token count
+    uint32_t* waux;              // [words] misses: byte offset of the word (its ids are at mtok[offset ...])
+    int32_t* mtok;               // [B+16]
+};
+
+struct GzAsmArgs {
+    GzTextBufs X[2];
+    int32_t n_texts;             // 1, or 2 in pair mode
+    int64_t n_docs;
+    int32_t dense, max_len;
+    int32_t* ids; int32_t* mask; int32_t* raw; int32_t* n_real;
+    int32_t docs_per_wave;
+};
+
+void gz_launch_pipeline_text(const GzDeviceTables* T_dev, const GzTextBufs& X, int64_t n_docs, int use_words, hipStream_t s);
+void gz_launch_assemble(const GzDeviceTables* T_dev, const GzAsmArgs& A, hipStream_t s);
+
 void gz_launch_encode(const GzDeviceTables* T_dev, const GzEncodeArgs& A, hipStream_t s);   // T_dev: device copy
 void gz_launch_rowscan(const GzFinalizeArgs& F, int64_t* row_len_tmp, hipStream_t s);
 void gz_launch_finalize(const GzDeviceTables& T, const GzFinalizeArgs& F, hipStream_t s);

@@ -245,8 +245,8 @@ __device__ __noinline__ int wave_merge(const GzDeviceTables* Tp, uint32_t* S, in
 
 // One word too long for a lane (or for a tile): bytes g[0..nbytes) in global memory, optional glued '\n'.
 // Returns the new token count, or -1 when the word needs the global arena and none was given (deferred).
-__device__ __noinline__ int long_word(const GzDeviceTables* Tp, WaveLds& L, const uint8_t* g, int64_t nbytes, bool glue,
-                                     uint32_t* arena_slot, Emit E, int lane)
+__device__ __noinline__ int long_word(const GzDeviceTables* Tp, uint32_t* lds_scratch, int lds_cap, const uint8_t* g,
+                                     int64_t nbytes, bool glue, uint32_t* arena_slot, Emit E, int lane)
 {
     const GzDeviceTables& T = *Tp;
     auto at = [&](int64_t i) -> uint32_t { return g[i]; };
@@ -255,7 +255,7 @@ __device__ __noinline__ int long_word(const GzDeviceTables* Tp, WaveLds& L, cons
     const int64_t nsym64 = (int64_t)wave_sum(leads) + (glue ? 1 : 0);
     uint32_t* S;
     bool global_scratch = false;
-    if (nsym64 <= LONGCAP) S = L.sym;
+    if (nsym64 <= lds_cap) S = lds_scratch;
     else if (arena_slot != nullptr) { S = arena_slot; global_scratch = true; }
     else return -1;
     int n = (int)nsym64;
@@ -662,7 +662,7 @@ __device__ __forceinline__ bool group_long_word(Group& G, int64_t gpos, int64_t 
     E.pad_hit = &G.L.pad_hit[doc];
     E.ntok = G.L.doc_ntok[doc];
     if (E.ntok < G.stop) {
-        const int nt = long_word(G.Tp, G.L, G.base + gpos, nbytes, glue, G.arena ? G.arena + gpos : nullptr, E, G.lane);
+        const int nt = long_word(G.Tp, G.L.sym, LONGCAP, G.base + gpos, nbytes, glue, G.arena ? G.arena + gpos : nullptr, E, G.lane);
         if (nt < 0) return false;
         if (G.lane == 0) G.L.doc_ntok[doc] = nt;
     }
@@ -1121,9 +1121,11 @@ __global__ __launch_bounds__(WAVE) void gz_bpe_word_kernel(const GzDeviceTables*
     const int lane = lane_id();
     Emit E;
     E.ids = nullptr; E.mask = nullptr; E.pad_hit = nullptr; E.symout = out; E.limit = cap; E.stop = 0x7FFFFFFF; E.ntok = 0; E.pad_id = Tp->pad_id;
-    const int nt = long_word(Tp, L, word, nbytes, false, arena, E, lane);
+    const int nt = long_word(Tp, L.sym, LONGCAP, word, nbytes, false, arena, E, lane);
     if (lane == 0) *n_out = nt;
 }
+
+#include "gz_pipeline.inc"
 
 // =================================================================================================================
 // launchers
