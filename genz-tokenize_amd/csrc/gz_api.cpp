@@ -165,11 +165,12 @@ int enqueue(gz_ctx* c, bool huge_pass)
     hipStream_t s = c->stream;
     p.A.huge_pass = huge_pass ? 1 : 0;
     p.A.arena = huge_pass ? (uint32_t*)c->w_arena.p : nullptr;
-    HIPCHK(c, hipMemsetAsync(c->w_flags.p, 0, 8, s));      // [0] defer, [1] capacity error
+    HIPCHK(c, hipMemsetAsync(c->w_flags.p, 0, 16, s));     // [0] defer, [1] capacity error, [3] a word needs the long path
     if (p.timing) HIPCHK(c, hipEventRecord(c->ev[0], s));
     if (p.pipeline) {
         for (int tx = 0; tx < p.S.n_texts; ++tx)
-            gz_launch_pipeline_text((const GzDeviceTables*)c->t_struct.p, p.S.X[tx], p.S.n_docs, p.use_words, s);
+            gz_launch_pipeline_text((const GzDeviceTables*)c->t_struct.p, p.S.X[tx], p.S.n_docs, p.use_words,
+                                    (int32_t*)c->w_flags.p + 3, s);
         gz_launch_assemble((const GzDeviceTables*)c->t_struct.p, p.S, s);
     } else {
         gz_launch_encode((const GzDeviceTables*)c->t_struct.p, p.A, s);
@@ -287,7 +288,7 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
         S2.n_docs = n_docs; S2.dense = A.dense; S2.max_len = max_len;
         S2.ids = input_ids; S2.mask = attention_mask; S2.raw = nullptr; S2.n_real = A.n_real;
         S2.docs_per_wave = A.docs_per_wave;
-        p.use_words = A.use_words;
+        p.use_words = A.use_words | (A.ablate << 8);
         for (int tx = 0; tx < S2.n_texts; ++tx) {
             GzTextBufs& X = S2.X[tx];
             gz_ctx::TextWs& W = c->tw[tx];

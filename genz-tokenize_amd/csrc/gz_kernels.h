@@ -79,7 +79,8 @@ struct GzAsmArgs {
     int32_t docs_per_wave;
 };
 
-void gz_launch_pipeline_text(const GzDeviceTables* T_dev, const GzTextBufs& X, int64_t n_docs, int use_words, hipStream_t s);
+void gz_launch_pipeline_text(const GzDeviceTables* T_dev, const GzTextBufs& X, int64_t n_docs, int use_words,
+                             int32_t* long_flag /* device int, zeroed by the caller */, hipStream_t s);
 void gz_launch_assemble(const GzDeviceTables* T_dev, const GzAsmArgs& A, hipStream_t s);
 
 void gz_launch_encode(const GzDeviceTables* T_dev, const GzEncodeArgs& A, hipStream_t s);   // T_dev: device copy
