@@ -94,8 +94,8 @@ struct gz_ctx {
     void* comm = nullptr;
     int rank = 0, world = 1;
 
-    DBuf t_words;
-    struct TextWs { DBuf brk, st, en, blkcnt, docw0, wtok, waux, mtok; } tw[2];
+    DBuf t_words, t_words2;
+    struct TextWs { DBuf brk, st, en, blkcnt, docw0, wtok, waux, mtok, mlist, blkmiss, blklong; } tw[2];
     bool use_pipeline = true;            // GZ_PIPELINE=0 selects the fused single-kernel path
     int64_t n_words = 0;
     bool building_words = false;         // the whole-word table is being built: ignore diagnostics
@@ -304,11 +304,13 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
             if ((rc2 = ensure(c, W.brk, bm)) || (rc2 = ensure(c, W.st, bm)) || (rc2 = ensure(c, W.en, bm)) ||
                 (rc2 = ensure(c, W.blkcnt, (size_t)(X.nblk + 2) * 4)) || (rc2 = ensure(c, W.docw0, (size_t)(n_docs + 2) * 4)) ||
                 (rc2 = ensure(c, W.wtok, (size_t)wmax * 4)) || (rc2 = ensure(c, W.waux, (size_t)wmax * 4)) ||
-                (rc2 = ensure(c, W.mtok, (size_t)(Bt + 32) * 4)))
+                (rc2 = ensure(c, W.mtok, (size_t)(Bt + 32) * 4)) || (rc2 = ensure(c, W.mlist, (size_t)wmax * 4)) ||
+                (rc2 = ensure(c, W.blkmiss, (size_t)(X.nblk + 2) * 4)) || (rc2 = ensure(c, W.blklong, (size_t)(X.nblk + 2) * 4)))
                 return rc2;
             X.brk = (uint16_t*)W.brk.p; X.st = (uint16_t*)W.st.p; X.en = (uint16_t*)W.en.p;
             X.blkcnt = (uint32_t*)W.blkcnt.p; X.docw0 = (uint32_t*)W.docw0.p;
             X.wtok = (uint32_t*)W.wtok.p; X.waux = (uint32_t*)W.waux.p; X.mtok = (int32_t*)W.mtok.p;
+            X.mlist = (uint32_t*)W.mlist.p; X.blkmiss = (uint32_t*)W.blkmiss.p; X.blklong = (uint32_t*)W.blklong.p;
         }
     }
     if (!dense) {
@@ -368,7 +370,7 @@ static int build_word_table(gz_ctx* c)
     std::vector<uint32_t> which;
     for (size_t s = 0; s < H.symbols.size(); ++s) {
         const std::string& str = H.symbols[s];
-        if (str.size() < 5 || str.size() > 20 || str.compare(str.size() - 4, 4, "</w>") != 0) continue;
+        if (str.size() < 5 || str.size() > 36 || str.compare(str.size() - 4, 4, "</w>") != 0) continue;
         const size_t n = str.size() - 4;
         if (!gz_is_plain_word((const uint8_t*)str.data(), n)) continue;     // contains whitespace: never one word
         text.insert(text.end(), str.begin(), str.begin() + n);
@@ -386,15 +388,36 @@ static int build_word_table(gz_ctx* c)
     c->building_words = false;
     if (rc) return rc;
     std::vector<GzWordSlot> found;
+    std::vector<GzWordSlot2> found2;
     for (int64_t i = 0; i < n; ++i) {
         if (row[i + 1] - row[i] != 3) continue;
         const int32_t id = ids[row[i] + 1];
         if (id < 0 || id >= (1 << 26)) continue;
-        GzWordSlot e{0, 0, (uint32_t)(off[i + 1] - off[i]), id, {0, 0}};
-        uint8_t key[16] = {0};
-        std::memcpy(key, text.data() + off[i], e.len);
-        std::memcpy(&e.lo, key, 8); std::memcpy(&e.hi, key + 8, 8);
-        found.push_back(e);
+        const uint32_t len = (uint32_t)(off[i + 1] - off[i]);
+        uint8_t key[32] = {0};
+        std::memcpy(key, text.data() + off[i], len);
+        if (len <= 16) {
+            GzWordSlot e{0, 0, len, id, {0, 0}};
+            std::memcpy(&e.lo, key, 8); std::memcpy(&e.hi, key + 8, 8);
+            found.push_back(e);
+        } else {
+            GzWordSlot2 e{{0, 0, 0, 0}, len, id, {0, 0, 0, 0, 0, 0}};
+            std::memcpy(e.k, key, 32);
+            found2.push_back(e);
+        }
+    }
+    if (!found2.empty()) {
+        size_t slots2 = 16;
+        while (slots2 < 2 * found2.size()) slots2 <<= 1;
+        std::vector<GzWordSlot2> tab2(slots2, GzWordSlot2{{0, 0, 0, 0}, 0, 0, {0, 0, 0, 0, 0, 0}});
+        for (const GzWordSlot2& e : found2) {
+            size_t h = gz_word_hash2(e.k, e.len) & (slots2 - 1);
+            while (tab2[h].len != 0) h = (h + 1) & (slots2 - 1);
+            tab2[h] = e;
+        }
+        if ((rc = upload(c, c->t_words2, tab2))) return rc;
+        c->dev.words2 = (const GzWordSlot2*)c->t_words2.p;
+        c->dev.word2_mask = (uint32_t)slots2 - 1;
     }
     if (found.empty()) return GZ_OK;
     size_t slots = 16;
@@ -456,12 +479,12 @@ void gz_destroy(gz_ctx* c)
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
-    for (DBuf* b : {&c->t_pair, &c->t_merges, &c->t_symids, &c->t_bmp, &c->t_astral, &c->t_struct, &c->t_words, &c->w_text, &c->w_toff, &c->w_pair,
+    for (DBuf* b : {&c->t_pair, &c->t_merges, &c->t_symids, &c->t_bmp, &c->t_astral, &c->t_struct, &c->t_words, &c->t_words2, &c->w_text, &c->w_toff, &c->w_pair,
                     &c->w_poff, &c->w_ids, &c->w_mask, &c->w_tt, &c->w_seq, &c->w_rowoff, &c->w_rowlen, &c->w_pairlen,
                     &c->w_nreal, &c->w_status, &c->w_raw, &c->w_arena, &c->w_flags, &c->w_word, &c->w_wordout})
         release(*b);
     for (auto& t : c->tw)
-        for (DBuf* b : {&t.brk, &t.st, &t.en, &t.blkcnt, &t.docw0, &t.wtok, &t.waux, &t.mtok}) release(*b);
+        for (DBuf* b : {&t.brk, &t.st, &t.en, &t.blkcnt, &t.docw0, &t.wtok, &t.waux, &t.mtok, &t.mlist, &t.blkmiss, &t.blklong}) release(*b);
     for (auto& ev : c->ev) if (ev) hipEventDestroy(ev);
     if (c->h_flags) hipHostFree(c->h_flags);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -504,7 +527,7 @@ int gz_load_tables(gz_ctx* c, const uint8_t* vocab, size_t vocab_len, const uint
     D.astral = H.astral.empty() ? nullptr : (const GzAstral*)c->t_astral.p;
     D.astral_mask = H.astral.empty() ? 0 : (uint32_t)H.astral.size() - 1;
     D.pad_id = H.special_ids[0]; D.bos_id = H.special_ids[1]; D.eos_id = H.special_ids[2]; D.unk_id = H.special_ids[4];
-    D.words = nullptr; D.word_mask = 0;
+    D.words = nullptr; D.word_mask = 0; D.words2 = nullptr; D.word2_mask = 0;
     if (c->host.enc_words.size() >= (1u << 26)) return fail(c, GZ_E_LIMIT, "vocab has 2^26 or more entries");
     if ((rc = ensure(c, c->t_struct, sizeof(GzDeviceTables)))) return rc;
     HIPCHK(c, hipMemcpy(c->t_struct.p, &c->dev, sizeof(GzDeviceTables), hipMemcpyHostToDevice));

@@ -61,6 +61,20 @@ GZ_HD uint32_t gz_word_hash(uint64_t lo, uint64_t hi, uint32_t len)
     return h;
 }
 
+// second whole-word table for words of 17..32 bytes (64-byte slots)
+struct GzWordSlot2 { uint64_t k[4]; uint32_t len; int32_t id; uint32_t pad[6]; };    // len == 0 -> empty
+GZ_HD uint32_t gz_word_hash2(const uint64_t k[4], uint32_t len)
+{
+    uint32_t h = len * 0x165667B1u;
+    for (int i = 0; i < 4; ++i) {
+        h ^= (uint32_t)k[i] * 0x9E3779B1u + (uint32_t)(k[i] >> 32) * 0x85EBCA6Bu;
+        h = (h << 13) | (h >> 19);
+        h *= 0xC2B2AE35u;
+    }
+    h ^= h >> 15;
+    return h;
+}
+
 // Device-resident tables, passed to kernels by value.
 struct GzDeviceTables {
     const GzPairSlot*  pair_tab;    uint32_t pair_mask;      // slots-1 (power of two)
@@ -70,6 +84,7 @@ struct GzDeviceTables {
     const GzAstral*    astral;      uint32_t astral_mask;    // slots-1; astral == nullptr when no astral symbol exists
     int32_t pad_id, bos_id, eos_id, unk_id;
     const GzWordSlot*  words;       uint32_t word_mask;      // nullptr until the whole-word table is built
+    const GzWordSlot2* words2;      uint32_t word2_mask;     // words of 17..32 bytes (may be nullptr)
 };
 
 // Host-side result of the loader (tokenize.py:31-57) and of the table build.

@@ -67,6 +67,9 @@ struct GzTextBufs {              // one text (A or B) of a batch and its per-cal
     uint32_t* docw0;             // [n_docs+1] index of each document's first word
     uint32_t* wtok;              // [words] id, or MISS | token count
     uint32_t* waux;              // [words] misses: byte offset of the word (its ids are at mtok[offset ...])
+    uint32_t* mlist;             // [words] the misses of block b, compact, at mlist[blkcnt[b] ...]
+    uint32_t* blkmiss;           // [nblk] number of misses per block
+    uint32_t* blklong;           // [nblk] block holds a word for gz_long_kernel (zeroed per call)
     int32_t* mtok;               // [B+16]
 };
 
