@@ -73,20 +73,18 @@ struct gz_ctx {
     // workspace
     DBuf w_text, w_toff, w_pair, w_poff, w_ids, w_mask, w_tt, w_seq, w_rowoff, w_rowlen, w_pairlen, w_nreal,
         w_status, w_raw, w_arena, w_flags, w_word, w_wordout;
-    int32_t* h_flags = nullptr;     // pinned: [0] defer, [1] capacity error, [2] bpe_word count
+    int32_t* h_flags = nullptr;     // pinned: [1] capacity error, [2] bpe_word count
 
     // the enqueued call (for gz_sync's arena pass)
     struct Pending {
         bool active = false;
-        GzEncodeArgs A{};
         bool ragged = false;
         GzFinalizeArgs F{};
         bool pair = false;
         GzPairArgs P{};
         bool timing = false;
-        bool pipeline = false;
         GzAsmArgs S{};
-        int use_words = 0;
+        int use_words = 0;             // bit 0: whole-word table; bits 8..: timing diagnostics (GZ_ABLATE)
     } pend;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     double timing[4] = {0, 0, 0, 0};
@@ -96,12 +94,9 @@ struct gz_ctx {
 
     DBuf t_words, t_words2;
     struct TextWs { DBuf brk, st, en, blkcnt, docw0, wtok, waux, mtok, mlist, blkmiss, blklong; } tw[2];
-    bool use_pipeline = true;            // GZ_PIPELINE=0 selects the fused single-kernel path
     int64_t n_words = 0;
     bool building_words = false;         // the whole-word table is being built: ignore diagnostics
     bool no_words_env = false;           // GZ_WORD_TABLE=0 in the environment
-    const int64_t* hint_off = nullptr;   // last device offsets array whose byte total was read back
-    int64_t hint_n = -1, hint_bytes = 0;
 };
 
 namespace {
@@ -159,22 +154,16 @@ GzShape make_shape(int32_t max_len, uint32_t flags)
 }
 
 // Enqueue every kernel of one call.  All pointers are device pointers.
-int enqueue(gz_ctx* c, bool huge_pass)
+int enqueue(gz_ctx* c)
 {
     gz_ctx::Pending& p = c->pend;
     hipStream_t s = c->stream;
-    p.A.huge_pass = huge_pass ? 1 : 0;
-    p.A.arena = huge_pass ? (uint32_t*)c->w_arena.p : nullptr;
-    HIPCHK(c, hipMemsetAsync(c->w_flags.p, 0, 16, s));     // [0] defer, [1] capacity error, [3] a word needs the long path
+    const GzDeviceTables* T = (const GzDeviceTables*)c->t_struct.p;
+    HIPCHK(c, hipMemsetAsync(c->w_flags.p, 0, 16, s));     // [1] capacity error, [3] a word needs the wide / long kernels
     if (p.timing) HIPCHK(c, hipEventRecord(c->ev[0], s));
-    if (p.pipeline) {
-        for (int tx = 0; tx < p.S.n_texts; ++tx)
-            gz_launch_pipeline_text((const GzDeviceTables*)c->t_struct.p, p.S.X[tx], p.S.n_docs, p.use_words,
-                                    (int32_t*)c->w_flags.p + 3, s);
-        gz_launch_assemble((const GzDeviceTables*)c->t_struct.p, p.S, s);
-    } else {
-        gz_launch_encode((const GzDeviceTables*)c->t_struct.p, p.A, s);
-    }
+    for (int tx = 0; tx < p.S.n_texts; ++tx)
+        gz_launch_pipeline_text(T, p.S.X[tx], p.S.n_docs, p.use_words, (int32_t*)c->w_flags.p + 3, s);
+    gz_launch_assemble(T, p.S, s);
     if (p.timing) HIPCHK(c, hipEventRecord(c->ev[1], s));
     if (p.ragged) {
         gz_launch_rowscan(p.F, (int64_t*)c->w_rowlen.p, s);
@@ -193,22 +182,6 @@ int sync_locked(gz_ctx* c)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     gz_ctx::Pending& p = c->pend;
     if (!p.active) return GZ_OK;
-    if (c->h_flags[0]) {
-        // some word exceeds the LDS long-word capacity: give the deferred documents a global arena
-        int64_t ends[2] = {0, 0}, begs[2] = {0, 0};
-        HIPCHK(c, hipMemcpy(&begs[0], p.A.text_off, 8, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(&ends[0], p.A.text_off + p.A.n_docs, 8, hipMemcpyDeviceToHost));
-        if (p.A.pair) {
-            HIPCHK(c, hipMemcpy(&begs[1], p.A.pair_off, 8, hipMemcpyDeviceToHost));
-            HIPCHK(c, hipMemcpy(&ends[1], p.A.pair_off + p.A.n_docs, 8, hipMemcpyDeviceToHost));
-        }
-        size_t total = (size_t)((ends[0] - begs[0]) + (ends[1] - begs[1]));
-        int rc = ensure(c, c->w_arena, total * 4 + 16);
-        if (rc) { p.active = false; return rc; }
-        rc = enqueue(c, true);
-        if (rc) { p.active = false; return rc; }
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-    }
     if (p.timing) {
         float ms = 0;
         hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); c->timing[0] = ms;
@@ -248,15 +221,8 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
     gz_ctx::Pending& p = c->pend;
     p = gz_ctx::Pending();
     p.timing = (flags & GZ_TIMING) != 0;
-    GzEncodeArgs& A = p.A;
-    A.text = text; A.text_off = text_off; A.pair = pair; A.pair_off = pair_off;
-    A.n_docs = n_docs; A.dense = dense ? 1 : 0; A.max_len = max_len;
-    A.ids = input_ids; A.mask = attention_mask; A.raw = nullptr; A.n_real = n_real;
-    A.defer_flag = (int32_t*)c->w_flags.p; A.arena = nullptr; A.huge_pass = 0;
-    A.use_words = (c->dev.words != nullptr && !(flags & GZ_NO_WORD_TABLE) && !c->no_words_env) ? 1 : 0;
-    // documents per wave: enough bytes per wave to fill its 1-KiB tiles, enough waves to fill the chip
     if (text_bytes < 0) {
-        // sizes of the batch: two 8-byte reads per text (the workspace is sized from them, so no stale hint here)
+        // sizes of the batch: two 8-byte reads per text (the workspace is sized from them)
         int64_t b[4] = {0, 0, 0, 0};
         HIPCHK(c, hipMemcpy(&b[0], text_off, 8, hipMemcpyDeviceToHost));
         HIPCHK(c, hipMemcpy(&b[1], text_off + n_docs, 8, hipMemcpyDeviceToHost));
@@ -268,74 +234,60 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
         pair_bytes = b[3] - b[2]; pair_beg = b[2];
         if (text_bytes < 0 || pair_bytes < 0) return fail(c, GZ_E_INVALID, "offsets are not non-decreasing");
     }
+    GzAsmArgs& S2 = p.S;
+    S2.n_texts = is_pair ? 2 : 1;
+    S2.n_docs = n_docs; S2.dense = dense ? 1 : 0; S2.max_len = max_len;
+    S2.ids = input_ids; S2.mask = attention_mask; S2.raw = nullptr; S2.n_real = n_real;
     {
+        // documents per wave of the assemble kernel: ~4 KiB of text per wave, but keep >= 16 K waves when possible
         const int64_t avg = n_docs > 0 ? text_bytes / n_docs : 0;
         int64_t dpw = avg > 0 ? 4096 / avg : GZ_MAX_DOCS_PER_WAVE;
-        const int64_t by_waves = n_docs / 16384;                 // keep >= 16 K waves when the batch allows it
+        const int64_t by_waves = n_docs / 16384;
         if (dpw > by_waves) dpw = by_waves;
         if (dpw < 1) dpw = 1;
         if (dpw > GZ_MAX_DOCS_PER_WAVE) dpw = GZ_MAX_DOCS_PER_WAVE;
-        A.docs_per_wave = (int32_t)dpw;
-        if (const char* e = getenv("GZ_DOCS_PER_WAVE")) { int v = atoi(e); if (v >= 1 && v <= GZ_MAX_DOCS_PER_WAVE) A.docs_per_wave = v; }
+        if (const char* e = getenv("GZ_DOCS_PER_WAVE")) { int v = atoi(e); if (v >= 1 && v <= GZ_MAX_DOCS_PER_WAVE) dpw = v; }
+        S2.docs_per_wave = (int32_t)dpw;
         const char* ab = getenv("GZ_ABLATE");       // timing diagnostics only: results are wrong when set
-        A.ablate = (ab && !c->building_words) ? atoi(ab) : 0;
-        A.table_build = c->building_words ? 1 : 0;
+        const int ablate = (ab && !c->building_words) ? atoi(ab) : 0;
+        const int use_words = (c->dev.words != nullptr && !(flags & GZ_NO_WORD_TABLE) && !c->no_words_env) ? 1 : 0;
+        p.use_words = use_words | (ablate << 8);
     }
-    p.pipeline = c->use_pipeline;
-    if (p.pipeline) {
-        GzAsmArgs& S2 = p.S;
-        S2.n_texts = is_pair ? 2 : 1;
-        S2.n_docs = n_docs; S2.dense = A.dense; S2.max_len = max_len;
-        S2.ids = input_ids; S2.mask = attention_mask; S2.raw = nullptr; S2.n_real = A.n_real;
-        S2.docs_per_wave = A.docs_per_wave;
-        p.use_words = A.use_words | (A.ablate << 8);
-        for (int tx = 0; tx < S2.n_texts; ++tx) {
-            GzTextBufs& X = S2.X[tx];
-            gz_ctx::TextWs& W = c->tw[tx];
-            const int64_t Bt = tx ? pair_bytes : text_bytes;
-            if (Bt >= (int64_t)0xFFFF0000ll) return fail(c, GZ_E_LIMIT, "a batch of 4 GiB or more of text must be split");
-            X.tb = (tx ? pair : text) + (tx ? pair_beg : text_beg);
-            X.off = tx ? pair_off : text_off;
-            X.B = Bt;
-            X.nblk = Bt / 4096 + 1;
-            const size_t bm = (size_t)((Bt + 1024) / 1024) * 128 + 64 + 4096;
-            int64_t wmax = Bt / 2 + n_docs + 2; if (wmax > Bt + 2) wmax = Bt + 2;
-            int rc2;
-            if ((rc2 = ensure(c, W.brk, bm)) || (rc2 = ensure(c, W.st, bm)) || (rc2 = ensure(c, W.en, bm)) ||
-                (rc2 = ensure(c, W.blkcnt, (size_t)(X.nblk + 2) * 4)) || (rc2 = ensure(c, W.docw0, (size_t)(n_docs + 2) * 4)) ||
-                (rc2 = ensure(c, W.wtok, (size_t)wmax * 4)) || (rc2 = ensure(c, W.waux, (size_t)wmax * 4)) ||
-                (rc2 = ensure(c, W.mtok, (size_t)(Bt + 32) * 4)) || (rc2 = ensure(c, W.mlist, (size_t)wmax * 4)) ||
-                (rc2 = ensure(c, W.blkmiss, (size_t)(X.nblk + 2) * 4)) || (rc2 = ensure(c, W.blklong, (size_t)(X.nblk + 2) * 4)))
-                return rc2;
-            X.brk = (uint16_t*)W.brk.p; X.st = (uint16_t*)W.st.p; X.en = (uint16_t*)W.en.p;
-            X.blkcnt = (uint32_t*)W.blkcnt.p; X.docw0 = (uint32_t*)W.docw0.p;
-            X.wtok = (uint32_t*)W.wtok.p; X.waux = (uint32_t*)W.waux.p; X.mtok = (int32_t*)W.mtok.p;
-            X.mlist = (uint32_t*)W.mlist.p; X.blkmiss = (uint32_t*)W.blkmiss.p; X.blklong = (uint32_t*)W.blklong.p;
-        }
+    for (int tx = 0; tx < S2.n_texts; ++tx) {
+        GzTextBufs& X = S2.X[tx];
+        gz_ctx::TextWs& W = c->tw[tx];
+        const int64_t Bt = tx ? pair_bytes : text_bytes;
+        if (Bt >= (int64_t)0xFFFF0000ll) return fail(c, GZ_E_LIMIT, "a batch of 4 GiB or more of text must be split");
+        X.tb = (tx ? pair : text) + (tx ? pair_beg : text_beg);
+        X.off = tx ? pair_off : text_off;
+        X.B = Bt;
+        X.nblk = Bt / 4096 + 1;
+        const size_t bm = (size_t)((Bt + 1024) / 1024) * 128 + 64 + 4096;
+        int64_t wmax = Bt / 2 + n_docs + 2; if (wmax > Bt + 2) wmax = Bt + 2;
+        int rc2;
+        if ((rc2 = ensure(c, W.brk, bm)) || (rc2 = ensure(c, W.st, bm)) || (rc2 = ensure(c, W.en, bm)) ||
+            (rc2 = ensure(c, W.blkcnt, (size_t)(X.nblk + 2) * 4)) || (rc2 = ensure(c, W.docw0, (size_t)(n_docs + 2) * 4)) ||
+            (rc2 = ensure(c, W.wtok, (size_t)wmax * 4)) || (rc2 = ensure(c, W.waux, (size_t)wmax * 4)) ||
+            (rc2 = ensure(c, W.mtok, (size_t)(Bt + 32) * 4)) || (rc2 = ensure(c, W.mlist, (size_t)wmax * 4)) ||
+            (rc2 = ensure(c, W.blkmiss, (size_t)(X.nblk + 2) * 4)) || (rc2 = ensure(c, W.blklong, (size_t)(X.nblk + 2) * 4)))
+            return rc2;
+        X.brk = (uint16_t*)W.brk.p; X.st = (uint16_t*)W.st.p; X.en = (uint16_t*)W.en.p;
+        X.blkcnt = (uint32_t*)W.blkcnt.p; X.docw0 = (uint32_t*)W.docw0.p;
+        X.wtok = (uint32_t*)W.wtok.p; X.waux = (uint32_t*)W.waux.p; X.mtok = (int32_t*)W.mtok.p;
+        X.mlist = (uint32_t*)W.mlist.p; X.blkmiss = (uint32_t*)W.blkmiss.p; X.blklong = (uint32_t*)W.blklong.p;
     }
     if (!dense) {
-        if (raw_elems < 0) {
-            int64_t b[4] = {0, 0, 0, 0};
-            HIPCHK(c, hipMemcpy(&b[0], text_off, 8, hipMemcpyDeviceToHost));
-            HIPCHK(c, hipMemcpy(&b[1], text_off + n_docs, 8, hipMemcpyDeviceToHost));
-            if (is_pair) {
-                HIPCHK(c, hipMemcpy(&b[2], pair_off, 8, hipMemcpyDeviceToHost));
-                HIPCHK(c, hipMemcpy(&b[3], pair_off + n_docs, 8, hipMemcpyDeviceToHost));
-            }
-            raw_elems = (b[1] - b[0]) + (b[3] - b[2]) + (is_pair ? 4 : 2) * n_docs;
-        }
+        if (raw_elems < 0) raw_elems = text_bytes + (is_pair ? pair_bytes : 0) + (is_pair ? 4 : 2) * n_docs;
         rc = ensure(c, c->w_raw, (size_t)raw_elems * 4 + 16); if (rc) return rc;
         rc = ensure(c, c->w_rowlen, (size_t)(n_docs + 1) * 8); if (rc) return rc;
-        A.raw = (int32_t*)c->w_raw.p;
-        p.S.raw = A.raw;
+        S2.raw = (int32_t*)c->w_raw.p;
         // raw token counts live in a private buffer: n_real is rewritten by the finalize kernel
         rc = ensure(c, c->w_status, (size_t)(n_docs + 1) * 4); if (rc) return rc;
-        A.n_real = (int32_t*)c->w_status.p;
-        p.S.n_real = A.n_real;
+        S2.n_real = (int32_t*)c->w_status.p;
         p.ragged = true;
         GzFinalizeArgs& F = p.F;
         F.text_off = text_off; F.pair_off = pair_off; F.n_docs = n_docs; F.S = S;
-        F.raw = A.raw; F.n_raw = A.n_real; F.row_off = row_off; F.capacity = capacity;
+        F.raw = S2.raw; F.n_raw = S2.n_real; F.row_off = row_off; F.capacity = capacity;
         F.ids = input_ids; F.mask = attention_mask; F.n_real = n_real;
         F.error_flag = (int32_t*)c->w_flags.p + 1;
     }
@@ -346,7 +298,7 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
         P.ids = input_ids; P.seq = sequence_id; P.tt = token_type_ids; P.pair_len = pair_len; P.status = status;
     }
     p.active = true;
-    rc = enqueue(c, false);
+    rc = enqueue(c);
     if (rc) p.active = false;
     return rc;
 }
@@ -466,7 +418,6 @@ int gz_create(int device_id, gz_ctx** out)
     }
     std::memset(c->h_flags, 0, 64);
     if (const char* e = getenv("GZ_WORD_TABLE")) c->no_words_env = (e[0] == '0');
-    if (const char* e = getenv("GZ_PIPELINE")) c->use_pipeline = (e[0] != '0');
     for (auto& ev : c->ev) hipEventCreate(&ev);
     if (ensure(c, c->w_flags, 64) != GZ_OK) { g_create_err = c->err; gz_destroy(c); return GZ_E_NOMEM; }
     *out = c;

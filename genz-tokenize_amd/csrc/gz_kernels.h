@@ -5,7 +5,6 @@
 
 constexpr int GZ_WAVES_PER_BLOCK = 2;
 constexpr int GZ_MAX_DOCS_PER_WAVE = 16;  // a wave owns up to this many consecutive documents
-constexpr int32_t GZ_DEFERRED = -1;     // n_real value of a document waiting for the arena pass
 constexpr int32_t GZ_NONE_ = -1;        // == GZ_NONE of the public header
 
 // max_len / padding / truncation of Tokenize.__call__ (tokenize.py:184-190)
@@ -13,26 +12,6 @@ struct GzShape {
     int32_t max_len;      // meaningful only when pad_mode
     int32_t pad_mode;     // `max_len is not None and padding` (tokenize.py:247, :256)
     int32_t truncation;
-};
-
-struct GzEncodeArgs {
-    const uint8_t* text;  const int64_t* text_off;
-    const uint8_t* pair;  const int64_t* pair_off;    // nullptr -> single-text mode
-    int64_t n_docs;
-    int32_t dense;        // rows of exactly max_len entries, written in place
-    int32_t max_len;
-    int32_t* ids;         // dense: [n_docs, max_len]
-    int32_t* mask;        // dense: [n_docs, max_len]
-    int32_t* raw;         // ragged: raw framed ids, document d at (text bytes before d) + (pair bytes before d) + 2d (+2d)
-    int32_t* n_real;      // [n_docs] dense: min(T, max_len); ragged: T (raw token count); GZ_DEFERRED
-    int32_t* defer_flag;  // set to 1 when some document needs the arena
-    uint32_t* arena;      // nullptr, or 4 bytes per input byte (text then pair)
-    int32_t huge_pass;    // 1: only groups whose first document has n_real == GZ_DEFERRED
-    int32_t docs_per_wave; // 1 .. GZ_MAX_DOCS_PER_WAVE (chosen by the host from the average document size)
-    int32_t use_words;     // consult the whole-word table (GzDeviceTables::words)
-    int32_t table_build;   // launched by the whole-word table build (separate kernel name for profiles)
-    int32_t ablate;        // timing diagnostics only (env GZ_ABLATE; results are WRONG when non-zero): 1 no merge loop,
-                           // 2 no miss decode/merge at all, 4 no token stores, 8 no pad/mask fill, 16 no tile classify
 };
 
 struct GzFinalizeArgs {
@@ -86,7 +65,6 @@ void gz_launch_pipeline_text(const GzDeviceTables* T_dev, const GzTextBufs& X, i
                              int32_t* long_flag /* device int, zeroed by the caller */, hipStream_t s);
 void gz_launch_assemble(const GzDeviceTables* T_dev, const GzAsmArgs& A, hipStream_t s);
 
-void gz_launch_encode(const GzDeviceTables* T_dev, const GzEncodeArgs& A, hipStream_t s);   // T_dev: device copy
 void gz_launch_rowscan(const GzFinalizeArgs& F, int64_t* row_len_tmp, hipStream_t s);
 void gz_launch_finalize(const GzDeviceTables& T, const GzFinalizeArgs& F, hipStream_t s);
 void gz_launch_pair(const GzDeviceTables& T, const GzPairArgs& P, hipStream_t s);
