@@ -32,10 +32,18 @@ for p in (ROOT, os.path.join(ROOT, "genz-tokenize_amd"), os.path.join(ROOT, "ora
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
-# HBM bytes per launch of gz_encode_kernel on the default workload, from the PMC passes kept in
-# profiles/r01_v2_pmc_traffic.txt: (FETCH_SIZE 1 468 443 KiB + WRITE_SIZE 3 265 434 KiB) * 1024 (separate --pmc runs;
-# read side not corrected for the gfx950 half-count of wide streaming reads: at most +0.14 GB)
-MEASURED_TRAFFIC_DEFAULT_WORKLOAD = (1468443 + 3265434) * 1024
+# HBM bytes per step (all kernels of the pipeline) on the default workload, from the PMC passes kept in
+# profiles/r01_v3_pmc_traffic.txt (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs; KiB summed over the kernels of
+# one step; the read side is not corrected for the gfx950 half-count of wide streaming reads)
+MEASURED_TRAFFIC_DEFAULT_WORKLOAD = None     # filled in below from profiles/ when present
+
+
+def _measured_traffic():
+    path = os.path.join(ROOT, "profiles", "r01_v3_pmc_traffic.json")
+    try:
+        return json.load(open(path))["bytes_per_step"]
+    except Exception:  # noqa: BLE001
+        return None
 
 
 def cpu_baseline(text, offs, max_len, budget_s=12.0):
@@ -225,12 +233,17 @@ def main():
                        "sharding": "dp%d by documents, RCCL gatherv of ids+mask to rank 0%s" % (
                            world, "" if gather or world == 1 else " DISABLED (--no-gather)") if world > 1 else "single GPU",
                        "inputs": "resident in HBM before the timed region"},
-            "roofline": {"bound": "hbm", "kernel": "gz_encode_kernel", "achieved": round(achieved, 2),
+            "roofline": {"bound": "hbm",
+                         "kernel": "the pipeline of one step, 9 launches on one stream: gz_brk, gz_classify, gz_scan32, gz_docw0, "
+                                   "gz_words, gz_miss, gz_miss_wide, gz_long, gz_assemble (longest: gz_miss_kernel)",
+                         "achieved": round(achieved, 2),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": MEASURED_TRAFFIC_DEFAULT_WORKLOAD if (n == 1_000_000 and L == 256) else None,
-                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, profiles/r01_v2_pmc_traffic.txt",
+                         "traffic": _measured_traffic() if (n == 1_000_000 and L == 256 and world == 1) else None,
+                         "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summed over the step's kernels, "
+                                           "profiles/r01_v3_pmc_traffic.json",
                          "algorithmic_bytes_per_launch": algo,
-                         "kernel_ms_avg": round(k_ms, 4), "timed_with": "hipEvents on the library's stream"},
+                         "kernel_ms_avg": round(k_ms, 4),
+                         "timed_with": "hipEvents on the library's stream around the step's launches"},
             "verified": verify,
             "merge_loop_only": merge_only,
         }
