@@ -653,6 +653,32 @@ int gz_encode_batch(gz_ctx* c, const uint8_t* text, const int64_t* text_off, con
                               attention_mask, token_type_ids, sequence_id, row_off, pair_len, n_real, status);
 }
 
+int gz_word_token_counts(gz_ctx* c, int which_text, int32_t* counts, int64_t capacity, int64_t* doc_first, int64_t* n_words)
+{
+    if (!c || !counts || !doc_first || !n_words || which_text < 0 || which_text > 1) return c ? fail(c, GZ_E_INVALID, "bad arguments") : GZ_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->pend.active) { int rc = sync_locked(c); if (rc) return rc; }
+    const GzAsmArgs& S = c->pend.S;
+    if (S.n_docs <= 0 || which_text >= S.n_texts) return fail(c, GZ_E_INVALID, "no encode call with that text to report on");
+    const GzTextBufs& X = S.X[which_text];
+    std::vector<uint32_t> dw((size_t)S.n_docs + 1);
+    HIPCHK(c, hipMemcpy(dw.data(), X.docw0, dw.size() * 4, hipMemcpyDeviceToHost));
+    // docw0[n_docs] is the rank of the last offset; the number of words is the scanned total
+    uint32_t total = 0;
+    HIPCHK(c, hipMemcpy(&total, X.blkcnt + X.nblk, 4, hipMemcpyDeviceToHost));
+    *n_words = total;
+    for (int64_t d = 0; d <= S.n_docs; ++d) doc_first[d] = dw[(size_t)d];
+    doc_first[S.n_docs] = total;
+    if ((int64_t)total > capacity) return fail(c, GZ_E_CAPACITY, "the batch has %u words, capacity is %lld", total, (long long)capacity);
+    if (total) {
+        std::vector<uint32_t> wt(total);
+        HIPCHK(c, hipMemcpy(wt.data(), X.wtok, (size_t)total * 4, hipMemcpyDeviceToHost));
+        for (uint32_t w = 0; w < total; ++w) counts[w] = (wt[w] & 0x80000000u) ? (int32_t)(wt[w] & 0x0FFFFFFFu) : 1;
+    }
+    return GZ_OK;
+}
+
 int64_t gz_bpe_word(gz_ctx* c, const uint8_t* word, int64_t len, int32_t* pieces, int64_t cap)
 {
     if (!c) return GZ_E_INVALID;

@@ -23,7 +23,7 @@ GZ_NONE = -1
 SYMBOLS = [
     "gz_version", "gz_create", "gz_destroy", "gz_last_error", "gz_load_tables", "gz_table_info",
     "gz_vocab_entry", "gz_merge_entry", "gz_encode_batch", "gz_encode_batch_device", "gz_sync",
-    "gz_bpe_word", "gz_symbol_utf8", "gz_device_alloc", "gz_device_free", "gz_memcpy_h2d", "gz_memcpy_d2h",
+    "gz_word_token_counts", "gz_bpe_word", "gz_symbol_utf8", "gz_device_alloc", "gz_device_free", "gz_memcpy_h2d", "gz_memcpy_d2h",
     "gz_timing", "gz_comm_unique_id", "gz_comm_init", "gz_gather_rows",
     "gz_host_tables_create", "gz_host_tables_destroy", "gz_host_tables_array", "gz_host_tables_vocab_entry",
     "gz_host_tables_merge_entry", "gz_host_tables_symbol",
@@ -62,6 +62,7 @@ def load_library():
     L.gz_encode_batch.argtypes = enc
     L.gz_encode_batch_device.argtypes = enc
     L.gz_sync.argtypes = [vp]
+    L.gz_word_token_counts.argtypes = [vp, C.c_int, vp, i64, vp, P(i64)]
     L.gz_bpe_word.argtypes = [vp, vp, i64, vp, i64]; L.gz_bpe_word.restype = i64
     L.gz_symbol_utf8.argtypes = [vp, i32, P(vp), P(i32)]
     L.gz_device_alloc.argtypes = [vp, sz, P(vp)]
@@ -213,6 +214,14 @@ class Context:
         if is_pair:
             out.update(token_type_ids=tt[:total], sequence_id=seq[:total], pair_len=pair_len[:2 * n].reshape(n, 2))
         return out
+
+    def word_token_counts(self, which_text: int, n_docs: int, capacity: int):
+        """(counts[int32, words], doc_first[int64, n_docs+1]) of the last encode call."""
+        counts = np.empty(max(capacity, 1), dtype=np.int32)
+        first = np.zeros(n_docs + 1, dtype=np.int64)
+        nw = C.c_int64()
+        self._check(self.lib.gz_word_token_counts(self.handle, which_text, _ptr(counts), capacity, _ptr(first), C.byref(nw)))
+        return counts[:nw.value], first
 
     def bpe_word(self, word: bytes):
         cap = len(word) + 1

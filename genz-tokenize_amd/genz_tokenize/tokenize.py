@@ -156,10 +156,21 @@ class Tokenize(object):
     def encode(self, sentence, return_offset) -> List[int]:
         """tokenize.py:126-135."""
         _require_str(sentence)
-        if return_offset:
-            raise NotImplementedError("return_offset is not implemented on the HIP path yet (SURVEY.md 8(f) row 1)")
         r = self._run([sentence], None, None, False, False)
-        return r["input_ids"].tolist()
+        ids = r["input_ids"].tolist()
+        if return_offset:
+            return ids, self._offsets(0, len(sentence.encode("utf-8", "surrogatepass")))
+        return ids
+
+    def _offsets(self, which_text, nbytes):
+        """tokenize.py:105, :111-117: [(0,0)] + one (first, last) 1-based token span per word + (T+1, T+1), from the
+        per-word piece counts of the last device call."""
+        counts, _ = self._ctx.word_token_counts(which_text, 1, nbytes // 1 + 2)
+        off, seen = [(0, 0)], 0
+        for c in counts.tolist():
+            off.append((seen + 1, seen + c)); seen += c
+        off.append((seen + 1, seen + 1))
+        return off
 
     def decode(self, token):
         """tokenize.py:137-139 (host side: string assembly)."""
@@ -203,14 +214,21 @@ class Tokenize(object):
         _require_str(text)
         if pair_text is not None:
             _require_str(pair_text)
-        if return_offset:
-            raise NotImplementedError("return_offset is not implemented on the HIP path yet (SURVEY.md 8(f) row 1)")
         if max_len is not None and not isinstance(max_len, (int, np.integer)):
             raise TypeError("max_len must be an int or None")
         r = self._run([text], None if pair_text is None else [pair_text], max_len, padding, truncation)
         if pair_text is not None and int(r["status"][0]) != 0:
             raise ValueError("None is not in list")                 # tokenize.py:157-160, rule P3
-        result = {'input_ids': r["input_ids"].tolist(), 'attention_mask': r["attention_mask"].tolist()}
+        result = {}
+        if return_offset:                                            # tokenize.py:225-234, :241-244 (first key, rule R1)
+            off = self._offsets(0, len(text.encode("utf-8", "surrogatepass")))
+            if pair_text is not None:
+                shift = len(off)                                     # entries of A, not tokens (rule O2)
+                off = off + [(a + shift, b + shift)
+                             for a, b in self._offsets(1, len(pair_text.encode("utf-8", "surrogatepass")))]
+            result['offset'] = off
+        result['input_ids'] = r["input_ids"].tolist()
+        result['attention_mask'] = r["attention_mask"].tolist()
         if pair_text is not None:
             ns, nt = (int(x) for x in r["pair_len"][0])
             seq = [None if v == _native.GZ_NONE else v for v in r["sequence_id"][:ns].tolist()]

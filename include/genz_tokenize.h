@@ -120,6 +120,13 @@ int  gz_encode_batch_device(gz_ctx *ctx,
                             int64_t *row_off, int32_t *pair_len, int32_t *n_real, int32_t *status);
 int  gz_sync(gz_ctx *ctx);
 
+/* Token count of every word of the LAST encode call (for `return_offset=True`, tokenize.py:105,111-117,225-244):
+ * which_text 0 = text, 1 = pair text.  counts[w] = pieces of word w (words of all documents, in order),
+ * doc_first[d] = index of document d's first word (n_docs+1 entries).  Returns GZ_E_CAPACITY (and *n_words)
+ * when the batch has more than `capacity` words.  Valid until the next encode call on the context. */
+int  gz_word_token_counts(gz_ctx *ctx, int which_text, int32_t *counts, int64_t capacity,
+                          int64_t *doc_first, int64_t *n_words);
+
 /* Tokenize.bpe(token) (tokenize.py:62-101) for one word: the pieces as interned symbol ids.
  * pieces[k] >= 0 is a symbol id (string via gz_symbol_utf8); pieces[k] < 0 is -(code point)-1 for a code
  * point that occurs in no merge and no vocab entry.  Returns the number of pieces or a GZ_E_* code
