@@ -83,7 +83,7 @@ struct gz_ctx {
         bool pair = false;
         GzPairArgs P{};
         bool timing = false;
-        GzAsmArgs S{};
+        std::vector<GzAsmArgs> subs;   // sub-batches of the call (contiguous document ranges)
         int use_words = 0;             // bit 0: whole-word table; bits 8..: timing diagnostics (GZ_ABLATE)
     } pend;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -93,7 +93,11 @@ struct gz_ctx {
     int rank = 0, world = 1;
 
     DBuf t_words, t_words2;
-    struct TextWs { DBuf brk, st, en, blkcnt, docw0, wtok, waux, mtok, mlist, blkmiss, blklong; } tw[2];
+    struct TextWs { DBuf brk, st, en, blkcnt, docw0, wtok, waux, mtok, mlist, blkmiss, blklong; } tw[2][2];   // [slot][text]
+    hipStream_t stream2 = nullptr;       // sub-batches alternate between the two streams
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    DBuf w_pick;
+    int64_t* h_pick = nullptr;           // pinned
     int64_t n_words = 0;
     bool building_words = false;         // the whole-word table is being built: ignore diagnostics
     bool no_words_env = false;           // GZ_WORD_TABLE=0 in the environment
@@ -153,7 +157,8 @@ GzShape make_shape(int32_t max_len, uint32_t flags)
     return S;
 }
 
-// Enqueue every kernel of one call.  All pointers are device pointers.
+// Enqueue every kernel of one call.  All pointers are device pointers.  Sub-batches alternate between two streams so
+// that the bandwidth-bound assemble kernel of one overlaps the issue-bound word / merge kernels of the next.
 int enqueue(gz_ctx* c)
 {
     gz_ctx::Pending& p = c->pend;
@@ -161,9 +166,16 @@ int enqueue(gz_ctx* c)
     const GzDeviceTables* T = (const GzDeviceTables*)c->t_struct.p;
     HIPCHK(c, hipMemsetAsync(c->w_flags.p, 0, 16, s));     // [1] capacity error, [3] a word needs the wide / long kernels
     if (p.timing) HIPCHK(c, hipEventRecord(c->ev[0], s));
-    for (int tx = 0; tx < p.S.n_texts; ++tx)
-        gz_launch_pipeline_text(T, p.S.X[tx], p.S.n_docs, p.use_words, (int32_t*)c->w_flags.p + 3, s);
-    gz_launch_assemble(T, p.S, s);
+    const bool two = p.subs.size() > 1;
+    if (two) { HIPCHK(c, hipEventRecord(c->ev_fork, s)); HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0)); }
+    for (size_t k = 0; k < p.subs.size(); ++k) {
+        hipStream_t sk = (k & 1) ? c->stream2 : s;
+        const GzAsmArgs& S = p.subs[k];
+        for (int tx = 0; tx < S.n_texts; ++tx)
+            gz_launch_pipeline_text(T, S.X[tx], S.n_docs, p.use_words, (int32_t*)c->w_flags.p + 3, sk);
+        gz_launch_assemble(T, S, sk);
+    }
+    if (two) { HIPCHK(c, hipEventRecord(c->ev_join, c->stream2)); HIPCHK(c, hipStreamWaitEvent(s, c->ev_join, 0)); }
     if (p.timing) HIPCHK(c, hipEventRecord(c->ev[1], s));
     if (p.ragged) {
         gz_launch_rowscan(p.F, (int64_t*)c->w_rowlen.p, s);
@@ -198,9 +210,7 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
                          const int64_t* pair_off, int64_t n_docs, int32_t max_len, uint32_t flags, int64_t capacity,
                          int32_t* input_ids, int32_t* attention_mask, int32_t* token_type_ids, int32_t* sequence_id,
                          int64_t* row_off, int32_t* pair_len, int32_t* n_real, int32_t* status,
-                         int64_t raw_elems /* < 0: unknown, read offsets from the device */,
-                         int64_t text_bytes /* < 0: unknown */, int64_t pair_bytes = -1, int64_t text_beg = 0,
-                         int64_t pair_beg = 0)
+                         const int64_t* h_text_off /* host copy of the offsets, or nullptr */, const int64_t* h_pair_off)
 {
     if (!c->have_tables) return fail(c, GZ_E_NOTABLES, "gz_load_tables has not been called");
     if (n_docs < 0 || !text_off || (n_docs > 0 && !text)) return fail(c, GZ_E_INVALID, "bad text arguments");
@@ -221,23 +231,31 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
     gz_ctx::Pending& p = c->pend;
     p = gz_ctx::Pending();
     p.timing = (flags & GZ_TIMING) != 0;
-    if (text_bytes < 0) {
-        // sizes of the batch: two 8-byte reads per text (the workspace is sized from them)
-        int64_t b[4] = {0, 0, 0, 0};
-        HIPCHK(c, hipMemcpy(&b[0], text_off, 8, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(&b[1], text_off + n_docs, 8, hipMemcpyDeviceToHost));
-        if (is_pair) {
-            HIPCHK(c, hipMemcpy(&b[2], pair_off, 8, hipMemcpyDeviceToHost));
-            HIPCHK(c, hipMemcpy(&b[3], pair_off + n_docs, 8, hipMemcpyDeviceToHost));
+
+    // Sub-batches: contiguous document ranges (dense layouts of large batches only).  Their byte positions are the
+    // only thing the host needs to know about the offsets: one tiny kernel + one 8*(2*nsub+2)-byte copy.
+    // (measured on cfg 3: 2 sub-batches on two streams gain 1.5 %, 4 gain nothing, 8 lose 10 % -- the kernels of one
+    // sub-batch already fill the chip -- so the default is one batch; GZ_SUB_BATCHES=k is kept for experiments)
+    int nsub = 1;
+    if (const char* e = getenv("GZ_SUB_BATCHES")) { int v = atoi(e); if (v >= 1 && v <= 8) nsub = (dense && n_docs >= 8 * v) ? v : 1; }
+    int64_t cutA[9], cutB[9];
+    if (h_text_off) {
+        for (int k = 0; k <= nsub; ++k) {
+            const int64_t d = (int64_t)k * n_docs / nsub;
+            cutA[k] = h_text_off[d];
+            cutB[k] = is_pair ? h_pair_off[d] : 0;
         }
-        text_bytes = b[1] - b[0]; text_beg = b[0];
-        pair_bytes = b[3] - b[2]; pair_beg = b[2];
-        if (text_bytes < 0 || pair_bytes < 0) return fail(c, GZ_E_INVALID, "offsets are not non-decreasing");
+    } else {
+        if ((rc = ensure(c, c->w_pick, 256))) return rc;
+        gz_launch_pick(text_off, pair_off, n_docs, nsub, (int64_t*)c->w_pick.p, c->stream);
+        HIPCHK(c, hipMemcpyAsync(c->h_pick, c->w_pick.p, (size_t)(2 * nsub + 2) * 8, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        for (int k = 0; k <= nsub; ++k) { cutA[k] = c->h_pick[k]; cutB[k] = c->h_pick[nsub + 1 + k]; }
     }
-    GzAsmArgs& S2 = p.S;
-    S2.n_texts = is_pair ? 2 : 1;
-    S2.n_docs = n_docs; S2.dense = dense ? 1 : 0; S2.max_len = max_len;
-    S2.ids = input_ids; S2.mask = attention_mask; S2.raw = nullptr; S2.n_real = n_real;
+    const int64_t text_bytes = cutA[nsub] - cutA[0], pair_bytes = is_pair ? cutB[nsub] - cutB[0] : 0;
+    if (text_bytes < 0 || pair_bytes < 0) return fail(c, GZ_E_INVALID, "offsets are not non-decreasing");
+
+    int docs_per_wave;
     {
         // documents per wave of the assemble kernel: ~4 KiB of text per wave, but keep >= 16 K waves when possible
         const int64_t avg = n_docs > 0 ? text_bytes / n_docs : 0;
@@ -247,47 +265,64 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
         if (dpw < 1) dpw = 1;
         if (dpw > GZ_MAX_DOCS_PER_WAVE) dpw = GZ_MAX_DOCS_PER_WAVE;
         if (const char* e = getenv("GZ_DOCS_PER_WAVE")) { int v = atoi(e); if (v >= 1 && v <= GZ_MAX_DOCS_PER_WAVE) dpw = v; }
-        S2.docs_per_wave = (int32_t)dpw;
+        docs_per_wave = (int)dpw;
         const char* ab = getenv("GZ_ABLATE");       // timing diagnostics only: results are wrong when set
         const int ablate = (ab && !c->building_words) ? atoi(ab) : 0;
         const int use_words = (c->dev.words != nullptr && !(flags & GZ_NO_WORD_TABLE) && !c->no_words_env) ? 1 : 0;
         p.use_words = use_words | (ablate << 8);
     }
-    for (int tx = 0; tx < S2.n_texts; ++tx) {
-        GzTextBufs& X = S2.X[tx];
-        gz_ctx::TextWs& W = c->tw[tx];
-        const int64_t Bt = tx ? pair_bytes : text_bytes;
-        if (Bt >= (int64_t)0xFFFF0000ll) return fail(c, GZ_E_LIMIT, "a batch of 4 GiB or more of text must be split");
-        X.tb = (tx ? pair : text) + (tx ? pair_beg : text_beg);
-        X.off = tx ? pair_off : text_off;
-        X.B = Bt;
-        X.nblk = Bt / 4096 + 1;
-        const size_t bm = (size_t)((Bt + 1024) / 1024) * 128 + 64 + 4096;
-        int64_t wmax = Bt / 2 + n_docs + 2; if (wmax > Bt + 2) wmax = Bt + 2;
-        int rc2;
-        if ((rc2 = ensure(c, W.brk, bm)) || (rc2 = ensure(c, W.st, bm)) || (rc2 = ensure(c, W.en, bm)) ||
-            (rc2 = ensure(c, W.blkcnt, (size_t)(X.nblk + 2) * 4)) || (rc2 = ensure(c, W.docw0, (size_t)(n_docs + 2) * 4)) ||
-            (rc2 = ensure(c, W.wtok, (size_t)wmax * 4)) || (rc2 = ensure(c, W.waux, (size_t)wmax * 4)) ||
-            (rc2 = ensure(c, W.mtok, (size_t)(Bt + 32) * 4)) || (rc2 = ensure(c, W.mlist, (size_t)wmax * 4)) ||
-            (rc2 = ensure(c, W.blkmiss, (size_t)(X.nblk + 2) * 4)) || (rc2 = ensure(c, W.blklong, (size_t)(X.nblk + 2) * 4)))
-            return rc2;
-        X.brk = (uint16_t*)W.brk.p; X.st = (uint16_t*)W.st.p; X.en = (uint16_t*)W.en.p;
-        X.blkcnt = (uint32_t*)W.blkcnt.p; X.docw0 = (uint32_t*)W.docw0.p;
-        X.wtok = (uint32_t*)W.wtok.p; X.waux = (uint32_t*)W.waux.p; X.mtok = (int32_t*)W.mtok.p;
-        X.mlist = (uint32_t*)W.mlist.p; X.blkmiss = (uint32_t*)W.blkmiss.p; X.blklong = (uint32_t*)W.blklong.p;
-    }
+    int32_t* raw = nullptr;
+    int32_t* n_raw = n_real;
     if (!dense) {
-        if (raw_elems < 0) raw_elems = text_bytes + (is_pair ? pair_bytes : 0) + (is_pair ? 4 : 2) * n_docs;
+        const int64_t raw_elems = text_bytes + pair_bytes + (is_pair ? 4 : 2) * n_docs;
         rc = ensure(c, c->w_raw, (size_t)raw_elems * 4 + 16); if (rc) return rc;
         rc = ensure(c, c->w_rowlen, (size_t)(n_docs + 1) * 8); if (rc) return rc;
-        S2.raw = (int32_t*)c->w_raw.p;
+        raw = (int32_t*)c->w_raw.p;
         // raw token counts live in a private buffer: n_real is rewritten by the finalize kernel
         rc = ensure(c, c->w_status, (size_t)(n_docs + 1) * 4); if (rc) return rc;
-        S2.n_real = (int32_t*)c->w_status.p;
+        n_raw = (int32_t*)c->w_status.p;
+    }
+    p.subs.resize((size_t)nsub);
+    for (int k = 0; k < nsub; ++k) {
+        const int64_t lo = (int64_t)k * n_docs / nsub, hi = (int64_t)(k + 1) * n_docs / nsub;
+        GzAsmArgs& S2 = p.subs[(size_t)k];
+        S2.n_texts = is_pair ? 2 : 1;
+        S2.n_docs = hi - lo; S2.dense = dense ? 1 : 0; S2.max_len = max_len;
+        S2.ids = input_ids + (dense ? lo * (int64_t)max_len : 0);
+        S2.mask = attention_mask + (dense ? lo * (int64_t)max_len : 0);
+        S2.raw = raw; S2.n_real = n_raw + lo;
+        S2.docs_per_wave = docs_per_wave;
+        for (int tx = 0; tx < S2.n_texts; ++tx) {
+            GzTextBufs& X = S2.X[tx];
+            gz_ctx::TextWs& W = c->tw[k & 1][tx];
+            const int64_t* cut = tx ? cutB : cutA;
+            const int64_t Bt = cut[k + 1] - cut[k];
+            if (Bt < 0) return fail(c, GZ_E_INVALID, "offsets are not non-decreasing");
+            if (Bt >= (int64_t)0xFFFF0000ll) return fail(c, GZ_E_LIMIT, "a batch of 4 GiB or more of text must be split");
+            X.tb = (tx ? pair : text) + cut[k];
+            X.off = (tx ? pair_off : text_off) + lo;
+            X.B = Bt;
+            X.nblk = Bt / 4096 + 1;
+            const size_t bm = (size_t)((Bt + 1024) / 1024) * 128 + 64 + 4096;
+            int64_t wmax = Bt / 2 + S2.n_docs + 2; if (wmax > Bt + 2) wmax = Bt + 2;
+            int rc2;
+            if ((rc2 = ensure(c, W.brk, bm)) || (rc2 = ensure(c, W.st, bm)) || (rc2 = ensure(c, W.en, bm)) ||
+                (rc2 = ensure(c, W.blkcnt, (size_t)(X.nblk + 2) * 4)) || (rc2 = ensure(c, W.docw0, (size_t)(S2.n_docs + 2) * 4)) ||
+                (rc2 = ensure(c, W.wtok, (size_t)wmax * 4)) || (rc2 = ensure(c, W.waux, (size_t)wmax * 4)) ||
+                (rc2 = ensure(c, W.mtok, (size_t)(Bt + 32) * 4)) || (rc2 = ensure(c, W.mlist, (size_t)wmax * 4)) ||
+                (rc2 = ensure(c, W.blkmiss, (size_t)(X.nblk + 2) * 4)) || (rc2 = ensure(c, W.blklong, (size_t)(X.nblk + 2) * 4)))
+                return rc2;
+            X.brk = (uint16_t*)W.brk.p; X.st = (uint16_t*)W.st.p; X.en = (uint16_t*)W.en.p;
+            X.blkcnt = (uint32_t*)W.blkcnt.p; X.docw0 = (uint32_t*)W.docw0.p;
+            X.wtok = (uint32_t*)W.wtok.p; X.waux = (uint32_t*)W.waux.p; X.mtok = (int32_t*)W.mtok.p;
+            X.mlist = (uint32_t*)W.mlist.p; X.blkmiss = (uint32_t*)W.blkmiss.p; X.blklong = (uint32_t*)W.blklong.p;
+        }
+    }
+    if (!dense) {
         p.ragged = true;
         GzFinalizeArgs& F = p.F;
         F.text_off = text_off; F.pair_off = pair_off; F.n_docs = n_docs; F.S = S;
-        F.raw = S2.raw; F.n_raw = S2.n_real; F.row_off = row_off; F.capacity = capacity;
+        F.raw = raw; F.n_raw = n_raw; F.row_off = row_off; F.capacity = capacity;
         F.ids = input_ids; F.mask = attention_mask; F.n_real = n_real;
         F.error_flag = (int32_t*)c->w_flags.p + 1;
     }
@@ -419,6 +454,10 @@ int gz_create(int device_id, gz_ctx** out)
     std::memset(c->h_flags, 0, 64);
     if (const char* e = getenv("GZ_WORD_TABLE")) c->no_words_env = (e[0] == '0');
     for (auto& ev : c->ev) hipEventCreate(&ev);
+    hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
+    hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+    hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+    hipHostMalloc((void**)&c->h_pick, 256, hipHostMallocDefault);
     if (ensure(c, c->w_flags, 64) != GZ_OK) { g_create_err = c->err; gz_destroy(c); return GZ_E_NOMEM; }
     *out = c;
     return GZ_OK;
@@ -429,12 +468,17 @@ void gz_destroy(gz_ctx* c)
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
+    if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); }
+    if (c->ev_fork) hipEventDestroy(c->ev_fork);
+    if (c->ev_join) hipEventDestroy(c->ev_join);
+    if (c->h_pick) hipHostFree(c->h_pick);
+    release(c->w_pick);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     for (DBuf* b : {&c->t_pair, &c->t_merges, &c->t_symids, &c->t_bmp, &c->t_astral, &c->t_struct, &c->t_words, &c->t_words2, &c->w_text, &c->w_toff, &c->w_pair,
                     &c->w_poff, &c->w_ids, &c->w_mask, &c->w_tt, &c->w_seq, &c->w_rowoff, &c->w_rowlen, &c->w_pairlen,
                     &c->w_nreal, &c->w_status, &c->w_raw, &c->w_arena, &c->w_flags, &c->w_word, &c->w_wordout})
         release(*b);
-    for (auto& t : c->tw)
+    for (auto& slot : c->tw) for (auto& t : slot)
         for (DBuf* b : {&t.brk, &t.st, &t.en, &t.blkcnt, &t.docw0, &t.wtok, &t.waux, &t.mtok, &t.mlist, &t.blkmiss, &t.blklong}) release(*b);
     for (auto& ev : c->ev) if (ev) hipEventDestroy(ev);
     if (c->h_flags) hipHostFree(c->h_flags);
@@ -538,7 +582,7 @@ int gz_encode_batch_device(gz_ctx* c, const uint8_t* text, const int64_t* text_o
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     return encode_device_locked(c, text, text_off, pair, pair_off, n_docs, max_len, flags, capacity, input_ids,
-                                attention_mask, token_type_ids, sequence_id, row_off, pair_len, n_real, status, -1, -1);
+                                attention_mask, token_type_ids, sequence_id, row_off, pair_len, n_real, status, nullptr, nullptr);
 }
 
 int gz_sync(gz_ctx* c)
@@ -609,8 +653,7 @@ static int encode_host_locked(gz_ctx* c, const uint8_t* text, const int64_t* tex
                               n_docs, max_len, flags, out_elems, (int32_t*)c->w_ids.p, (int32_t*)c->w_mask.p,
                               is_pair ? (int32_t*)c->w_tt.p : nullptr, is_pair ? (int32_t*)c->w_seq.p : nullptr,
                               (int64_t*)c->w_rowoff.p, is_pair ? (int32_t*)c->w_pairlen.p : nullptr,
-                              (int32_t*)c->w_nreal.p, is_pair ? (int32_t*)st2.p : nullptr, raw_elems, tb, pb,
-                              text_off[0], is_pair ? pair_off[0] : 0);
+                              (int32_t*)c->w_nreal.p, is_pair ? (int32_t*)st2.p : nullptr, text_off, pair_off);
     if (rc == GZ_OK) rc = sync_locked(c);
     if (rc) { release(st2); return rc; }
 
@@ -659,23 +702,30 @@ int gz_word_token_counts(gz_ctx* c, int which_text, int32_t* counts, int64_t cap
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     if (c->pend.active) { int rc = sync_locked(c); if (rc) return rc; }
-    const GzAsmArgs& S = c->pend.S;
-    if (S.n_docs <= 0 || which_text >= S.n_texts) return fail(c, GZ_E_INVALID, "no encode call with that text to report on");
-    const GzTextBufs& X = S.X[which_text];
-    std::vector<uint32_t> dw((size_t)S.n_docs + 1);
-    HIPCHK(c, hipMemcpy(dw.data(), X.docw0, dw.size() * 4, hipMemcpyDeviceToHost));
-    // docw0[n_docs] is the rank of the last offset; the number of words is the scanned total
-    uint32_t total = 0;
-    HIPCHK(c, hipMemcpy(&total, X.blkcnt + X.nblk, 4, hipMemcpyDeviceToHost));
-    *n_words = total;
-    for (int64_t d = 0; d <= S.n_docs; ++d) doc_first[d] = dw[(size_t)d];
-    doc_first[S.n_docs] = total;
-    if ((int64_t)total > capacity) return fail(c, GZ_E_CAPACITY, "the batch has %u words, capacity is %lld", total, (long long)capacity);
-    if (total) {
-        std::vector<uint32_t> wt(total);
-        HIPCHK(c, hipMemcpy(wt.data(), X.wtok, (size_t)total * 4, hipMemcpyDeviceToHost));
-        for (uint32_t w = 0; w < total; ++w) counts[w] = (wt[w] & 0x80000000u) ? (int32_t)(wt[w] & 0x0FFFFFFFu) : 1;
+    const std::vector<GzAsmArgs>& subs = c->pend.subs;
+    if (subs.empty() || which_text >= subs[0].n_texts) return fail(c, GZ_E_INVALID, "no encode call with that text to report on");
+    if (subs.size() > 2) return fail(c, GZ_E_INVALID, "word counts are kept for batches of fewer than 65536 documents only");
+    int64_t wbase = 0, dbase = 0;
+    for (const GzAsmArgs& S : subs) {
+        const GzTextBufs& X = S.X[which_text];
+        std::vector<uint32_t> dw((size_t)S.n_docs + 1);
+        HIPCHK(c, hipMemcpy(dw.data(), X.docw0, dw.size() * 4, hipMemcpyDeviceToHost));
+        uint32_t total = 0;                                      // the scanned block counts end with the word total
+        HIPCHK(c, hipMemcpy(&total, X.blkcnt + X.nblk, 4, hipMemcpyDeviceToHost));
+        for (int64_t d = 0; d < S.n_docs; ++d) doc_first[dbase + d] = wbase + dw[(size_t)d];
+        if (wbase + (int64_t)total > capacity) {
+            *n_words = wbase + total;
+            return fail(c, GZ_E_CAPACITY, "the batch has more than %lld words", (long long)capacity);
+        }
+        if (total) {
+            std::vector<uint32_t> wt(total);
+            HIPCHK(c, hipMemcpy(wt.data(), X.wtok, (size_t)total * 4, hipMemcpyDeviceToHost));
+            for (uint32_t w = 0; w < total; ++w) counts[wbase + w] = (wt[w] & 0x80000000u) ? (int32_t)(wt[w] & 0x0FFFFFFFu) : 1;
+        }
+        wbase += total; dbase += S.n_docs;
     }
+    doc_first[dbase] = wbase;
+    *n_words = wbase;
     return GZ_OK;
 }
 

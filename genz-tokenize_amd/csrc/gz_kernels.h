@@ -63,6 +63,7 @@ struct GzAsmArgs {
 
 void gz_launch_pipeline_text(const GzDeviceTables* T_dev, const GzTextBufs& X, int64_t n_docs, int use_words,
                              int32_t* long_flag /* device int, zeroed by the caller */, hipStream_t s);
+void gz_launch_pick(const int64_t* off, const int64_t* off2, int64_t n_docs, int nsub, int64_t* out /* 2*(nsub+1) */, hipStream_t s);
 void gz_launch_assemble(const GzDeviceTables* T_dev, const GzAsmArgs& A, hipStream_t s);
 
 void gz_launch_rowscan(const GzFinalizeArgs& F, int64_t* row_len_tmp, hipStream_t s);

@@ -455,6 +455,21 @@ __global__ __launch_bounds__(WAVE) void gz_bpe_word_kernel(const GzDeviceTables*
     if (lane == 0) *n_out = nt;
 }
 
+// off[(s * n_docs) / nsub] for s = 0 .. nsub: the byte positions where a batch is cut into sub-batches
+__global__ void gz_pick_kernel(const int64_t* off, const int64_t* off2, int64_t n_docs, int nsub, int64_t* out)
+{
+    const int s = threadIdx.x;
+    if (s > nsub) return;
+    const int64_t d = (int64_t)s * n_docs / nsub;
+    out[s] = off[d];
+    out[nsub + 1 + s] = off2 ? off2[d] : 0;
+}
+
+void gz_launch_pick(const int64_t* off, const int64_t* off2, int64_t n_docs, int nsub, int64_t* out, hipStream_t s)
+{
+    hipLaunchKernelGGL(gz_pick_kernel, dim3(1), dim3(64), 0, s, off, off2, n_docs, nsub, out);
+}
+
 #include "gz_pipeline.inc"
 
 // =================================================================================================================
