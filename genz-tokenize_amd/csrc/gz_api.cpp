@@ -92,7 +92,7 @@ struct gz_ctx {
     void* comm = nullptr;
     int rank = 0, world = 1;
 
-    DBuf t_words, t_words2;
+    DBuf t_words2, t_words0;
     struct TextWs { DBuf brk, st, en, blkcnt, docw0, wtok, waux, mtok, mlist, blkmiss, blklong; } tw[2][2];   // [slot][text]
     hipStream_t stream2 = nullptr;       // sub-batches alternate between the two streams
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -268,7 +268,7 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
         docs_per_wave = (int)dpw;
         const char* ab = getenv("GZ_ABLATE");       // timing diagnostics only: results are wrong when set
         const int ablate = (ab && !c->building_words) ? atoi(ab) : 0;
-        const int use_words = (c->dev.words != nullptr && !(flags & GZ_NO_WORD_TABLE) && !c->no_words_env) ? 1 : 0;
+        const int use_words = (c->dev.words0 != nullptr && !(flags & GZ_NO_WORD_TABLE) && !c->no_words_env) ? 1 : 0;
         p.use_words = use_words | (ablate << 8);
     }
     int32_t* raw = nullptr;
@@ -374,8 +374,8 @@ static int build_word_table(gz_ctx* c)
                                 ids.data(), mask.data(), nullptr, nullptr, row.data(), nullptr, nreal.data(), nullptr);
     c->building_words = false;
     if (rc) return rc;
-    std::vector<GzWordSlot> found;
     std::vector<GzWordSlot2> found2;
+    std::vector<GzWordSlot0> found0;
     for (int64_t i = 0; i < n; ++i) {
         if (row[i + 1] - row[i] != 3) continue;
         const int32_t id = ids[row[i] + 1];
@@ -383,15 +383,29 @@ static int build_word_table(gz_ctx* c)
         const uint32_t len = (uint32_t)(off[i + 1] - off[i]);
         uint8_t key[32] = {0};
         std::memcpy(key, text.data() + off[i], len);
-        if (len <= 16) {
-            GzWordSlot e{0, 0, len, id, {0, 0}};
-            std::memcpy(&e.lo, key, 8); std::memcpy(&e.hi, key + 8, 8);
-            found.push_back(e);
+        if (len <= 12) {
+            GzWordSlot0 e{0, 0, len | ((uint32_t)id << 4)};
+            std::memcpy(&e.lo, key, 8); std::memcpy(&e.hi, key + 8, 4);
+            found0.push_back(e);
         } else {
             GzWordSlot2 e{{0, 0, 0, 0}, len, id, {0, 0, 0, 0, 0, 0}};
             std::memcpy(e.k, key, 32);
             found2.push_back(e);
         }
+    }
+    if (found0.empty()) return GZ_OK;            // (the 13..32-byte table is only consulted for misses of the first)
+    {
+        size_t slots0 = 16;
+        while (slots0 < 2 * found0.size()) slots0 <<= 1;
+        std::vector<GzWordSlot0> tab0(slots0, GzWordSlot0{0, 0, 0});
+        for (const GzWordSlot0& e : found0) {
+            size_t h = gz_word_hash0(e.lo, e.hi, e.meta & 15u) & (slots0 - 1);
+            while (tab0[h].meta != 0) h = (h + 1) & (slots0 - 1);
+            tab0[h] = e;
+        }
+        if ((rc = upload(c, c->t_words0, tab0))) return rc;
+        c->dev.words0 = (const GzWordSlot0*)c->t_words0.p;
+        c->dev.word0_mask = (uint32_t)slots0 - 1;
     }
     if (!found2.empty()) {
         size_t slots2 = 16;
@@ -406,21 +420,9 @@ static int build_word_table(gz_ctx* c)
         c->dev.words2 = (const GzWordSlot2*)c->t_words2.p;
         c->dev.word2_mask = (uint32_t)slots2 - 1;
     }
-    if (found.empty()) return GZ_OK;
-    size_t slots = 16;
-    while (slots < 2 * found.size()) slots <<= 1;
-    std::vector<GzWordSlot> tab(slots, GzWordSlot{0, 0, 0, 0, {0, 0}});
-    for (const GzWordSlot& e : found) {
-        size_t h = gz_word_hash(e.lo, e.hi, e.len) & (slots - 1);
-        while (tab[h].len != 0) h = (h + 1) & (slots - 1);
-        tab[h] = e;
-    }
-    if ((rc = upload(c, c->t_words, tab))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->dev.words = (const GzWordSlot*)c->t_words.p;
-    c->dev.word_mask = (uint32_t)slots - 1;
     HIPCHK(c, hipMemcpy(c->t_struct.p, &c->dev, sizeof(GzDeviceTables), hipMemcpyHostToDevice));
-    c->n_words = (int64_t)found.size();
+    c->n_words = (int64_t)(found0.size() + found2.size());
     return GZ_OK;
 }
 
@@ -474,7 +476,7 @@ void gz_destroy(gz_ctx* c)
     if (c->h_pick) hipHostFree(c->h_pick);
     release(c->w_pick);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
-    for (DBuf* b : {&c->t_pair, &c->t_merges, &c->t_symids, &c->t_bmp, &c->t_astral, &c->t_struct, &c->t_words, &c->t_words2, &c->w_text, &c->w_toff, &c->w_pair,
+    for (DBuf* b : {&c->t_pair, &c->t_merges, &c->t_symids, &c->t_bmp, &c->t_astral, &c->t_struct, &c->t_words2, &c->t_words0, &c->w_text, &c->w_toff, &c->w_pair,
                     &c->w_poff, &c->w_ids, &c->w_mask, &c->w_tt, &c->w_seq, &c->w_rowoff, &c->w_rowlen, &c->w_pairlen,
                     &c->w_nreal, &c->w_status, &c->w_raw, &c->w_arena, &c->w_flags, &c->w_word, &c->w_wordout})
         release(*b);
@@ -522,7 +524,7 @@ int gz_load_tables(gz_ctx* c, const uint8_t* vocab, size_t vocab_len, const uint
     D.astral = H.astral.empty() ? nullptr : (const GzAstral*)c->t_astral.p;
     D.astral_mask = H.astral.empty() ? 0 : (uint32_t)H.astral.size() - 1;
     D.pad_id = H.special_ids[0]; D.bos_id = H.special_ids[1]; D.eos_id = H.special_ids[2]; D.unk_id = H.special_ids[4];
-    D.words = nullptr; D.word_mask = 0; D.words2 = nullptr; D.word2_mask = 0;
+    D.words2 = nullptr; D.word2_mask = 0; D.words0 = nullptr; D.word0_mask = 0;
     if (c->host.enc_words.size() >= (1u << 26)) return fail(c, GZ_E_LIMIT, "vocab has 2^26 or more entries");
     if ((rc = ensure(c, c->t_struct, sizeof(GzDeviceTables)))) return rc;
     HIPCHK(c, hipMemcpy(c->t_struct.p, &c->dev, sizeof(GzDeviceTables), hipMemcpyHostToDevice));

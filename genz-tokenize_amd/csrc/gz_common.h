@@ -48,20 +48,19 @@ struct GzMergeInfo { uint32_t left, right, merged, pad; };   // indexed by rank
 struct GzSymIds    { int32_t nonfinal, final_; };            // vocab id of  sym+"@@"  /  sym minus "</w>"
 struct GzCpSyms    { uint32_t plain, final_; };              // symbol of  c  /  c+"</w>"   (GZ_NO_SYMBOL if none)
 struct GzAstral    { uint32_t cp, plain, final_, pad; };     // open-addressing entry, cp == GZ_NO_SYMBOL -> empty
-// whole-word table: word bytes (<= 16, zero padded) -> the single vocab id bpe() yields for that word.
-// Built at table-load time by running the GPU merge path itself over every candidate word (gz_api.cpp).
-struct GzWordSlot  { uint64_t lo, hi; uint32_t len; int32_t id; uint32_t pad[2]; };   // len == 0 -> empty
-GZ_HD uint32_t gz_word_hash(uint64_t lo, uint64_t hi, uint32_t len)
+// Whole-word tables: word bytes -> the single vocab id bpe() yields for that word.  Built at table-load time by
+// running the GPU merge path itself over every candidate word (gz_api.cpp).
+// first whole-word table: words of <= 12 bytes (96 % of running text) in 16-byte slots -> ONE 16-byte load per probe
+struct GzWordSlot0 { uint64_t lo; uint32_t hi; uint32_t meta; };        // meta = len:4 | id << 4;  0 -> empty
+GZ_HD uint32_t gz_word_hash0(uint64_t lo, uint32_t hi, uint32_t len)
 {
-    uint32_t h = (uint32_t)lo * 0x9E3779B1u ^ (uint32_t)(lo >> 32) * 0x85EBCA6Bu ^
-                 (uint32_t)hi * 0xC2B2AE35u ^ (uint32_t)(hi >> 32) * 0x27D4EB2Fu ^ len * 0x165667B1u;
+    uint32_t h = (uint32_t)lo * 0x9E3779B1u ^ (uint32_t)(lo >> 32) * 0x85EBCA6Bu ^ hi * 0xC2B2AE35u ^ len * 0x165667B1u;
     h ^= h >> 15;
     h *= 0x2C1B3C6Du;
     h ^= h >> 13;
     return h;
 }
-
-// second whole-word table for words of 17..32 bytes (64-byte slots)
+// second whole-word table: words of 13..32 bytes (64-byte slots), probed by the miss kernel
 struct GzWordSlot2 { uint64_t k[4]; uint32_t len; int32_t id; uint32_t pad[6]; };    // len == 0 -> empty
 GZ_HD uint32_t gz_word_hash2(const uint64_t k[4], uint32_t len)
 {
@@ -83,8 +82,8 @@ struct GzDeviceTables {
     const GzCpSyms*    bmp;                                   // 65536 entries
     const GzAstral*    astral;      uint32_t astral_mask;    // slots-1; astral == nullptr when no astral symbol exists
     int32_t pad_id, bos_id, eos_id, unk_id;
-    const GzWordSlot*  words;       uint32_t word_mask;      // nullptr until the whole-word table is built
-    const GzWordSlot2* words2;      uint32_t word2_mask;     // words of 17..32 bytes (may be nullptr)
+    const GzWordSlot0* words0;      uint32_t word0_mask;     // whole-word table, <= 12 bytes (nullptr until built)
+    const GzWordSlot2* words2;      uint32_t word2_mask;     // whole-word table, 13..32 bytes (may be nullptr)
 };
 
 // Host-side result of the loader (tokenize.py:31-57) and of the table build.
