@@ -79,6 +79,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--docs", type=int, default=1_000_000, help="documents per GPU")
     ap.add_argument("--no-gather", action="store_true", help="(diagnostic) skip the RCCL gather at N > 1")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="(diagnostic) run the multi-GPU exchange step even with one rank (launch through torch.distributed.run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-merge-only", action="store_true", help="skip the secondary run without the whole-word table")
@@ -96,7 +98,7 @@ def main():
     import torch
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or args.force_exchange:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
@@ -116,17 +118,39 @@ def main():
     d_ids = ctx.alloc(4 * n * L); d_mask = ctx.alloc(4 * n * L); d_nreal = ctx.alloc(4 * n)
     flags = _native.GZ_PADDING | _native.GZ_TRUNCATION | _native.GZ_TIMING
 
-    gather = world > 1 and not args.no_gather
-    d_all_ids = d_all_mask = 0
+    gather = (world > 1 or args.force_exchange) and not args.no_gather
+    d_all_ids = d_all_mask = d_all_nreal = d_comp = 0
+    all_comp = {"ptr": 0, "cap": 0}
     rows_per_rank = [n] * world
     if gather:
         uid = [ctx.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         ctx.comm_init(uid[0], rank, world)
+        d_comp = ctx.alloc(4 * n * L)                      # the rank's rows without their padding (worst case: all of it)
         if rank == 0:
             d_all_ids = ctx.alloc(4 * n * L * world); d_all_mask = ctx.alloc(4 * n * L * world)
+            d_all_nreal = ctx.alloc(4 * n * world)
 
     kernel_ms = []
+
+    def exchange():
+        """The exchange step: every rank sends its rows WITHOUT the padding (row lengths + leading entries) straight to
+        rank 0 over its own xGMI link (grouped ncclSend/ncclRecv); rank 0 re-creates padding and attention mask."""
+        total = ctx.compact_rows(d_ids, d_nreal, n, L, d_comp)
+        t = torch.tensor([total], dtype=torch.int64, device="cuda")
+        lst = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(lst, t)
+        totals = [int(x.item()) for x in lst]
+        if rank == 0 and sum(totals) > all_comp["cap"]:
+            if all_comp["ptr"]:
+                ctx.free(all_comp["ptr"])
+            all_comp["cap"] = int(sum(totals) * 1.05) + 1024
+            all_comp["ptr"] = ctx.alloc(4 * all_comp["cap"])
+        ctx.gather_rows(d_nreal, n, 1, d_all_nreal, rows_per_rank, 0)
+        ctx.gather_rows(d_comp, total, 1, all_comp["ptr"], totals, 0)
+        if rank == 0:
+            ctx.expand_rows(all_comp["ptr"], d_all_nreal, n * world, L, d_all_ids, d_all_mask)
+        ctx.sync()
 
     def step(record):
         ctx.encode_device(d_text, d_off, 0, 0, n, L, flags, n * L, d_ids, d_mask, d_n_real=d_nreal)
@@ -134,9 +158,7 @@ def main():
         if record:
             kernel_ms.append(ctx.timing()[0])
         if gather:
-            ctx.gather_rows(d_ids, n, L, d_all_ids, rows_per_rank, 0)
-            ctx.gather_rows(d_mask, n, L, d_all_mask, rows_per_rank, 0)
-            ctx.sync()
+            exchange()
 
     def fence():
         if dist is not None:
@@ -205,10 +227,11 @@ def main():
                     sys.exit("bench: document %d differs from the oracle" % i)
             verify = "oracle on a 200-document stride sample: match"
         if gather:
-            allids = np.empty((n * world, L), dtype=np.int32); ctx.d2h(allids, d_all_ids)
-            if not np.array_equal(allids[:n], ids):
+            blk = np.empty((n, L), dtype=np.int32); ctx.d2h(blk, d_all_ids)
+            mblk = np.empty((n, L), dtype=np.int32); ctx.d2h(mblk, d_all_mask)
+            if not (np.array_equal(blk, ids) and np.array_equal(mblk, mask)):
                 sys.exit("bench: gathered block of rank 0 differs from its local rows")
-            verify += "; gathered [%d, %d] block checked for rank 0" % (n * world, L)
+            verify += "; gathered [%d, %d] ids+mask: rank 0's block equals its local rows" % (n * world, L)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -230,7 +253,7 @@ def main():
                                    "5%% 121-400 words), max_len=%d pad+trunc, bundled vocab" % (n, L),
                        "docs_total": total_docs, "input_bytes_total": int(total_bytes),
                        "tokens_total": int(total_tokens),
-                       "sharding": "dp%d by documents, RCCL gatherv of ids+mask to rank 0%s" % (
+                       "sharding": "dp%d by documents; exchange = RCCL gatherv (grouped send/recv) of row lengths + unpadded ids to rank 0, which rebuilds padding and mask%s" % (
                            world, "" if gather or world == 1 else " DISABLED (--no-gather)") if world > 1 else "single GPU",
                        "inputs": "resident in HBM before the timed region"},
             "roofline": {"bound": "hbm",

@@ -96,7 +96,7 @@ struct gz_ctx {
     struct TextWs { DBuf brk, st, en, blkcnt, docw0, wtok, waux, mtok, mlist, blkmiss, blklong; } tw[2][2];   // [slot][text]
     hipStream_t stream2 = nullptr;       // sub-batches alternate between the two streams
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    DBuf w_pick;
+    DBuf w_pick, w_rowoff32;
     int64_t* h_pick = nullptr;           // pinned
     int64_t n_words = 0;
     bool building_words = false;         // the whole-word table is being built: ignore diagnostics
@@ -474,7 +474,7 @@ void gz_destroy(gz_ctx* c)
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->h_pick) hipHostFree(c->h_pick);
-    release(c->w_pick);
+    release(c->w_pick); release(c->w_rowoff32);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     for (DBuf* b : {&c->t_pair, &c->t_merges, &c->t_symids, &c->t_bmp, &c->t_astral, &c->t_struct, &c->t_words2, &c->t_words0, &c->w_text, &c->w_toff, &c->w_pair,
                     &c->w_poff, &c->w_ids, &c->w_mask, &c->w_tt, &c->w_seq, &c->w_rowoff, &c->w_rowlen, &c->w_pairlen,
@@ -797,6 +797,44 @@ int gz_timing(gz_ctx* c, double out_ms[4])
 {
     if (!c || !out_ms) return GZ_E_INVALID;
     for (int i = 0; i < 4; ++i) out_ms[i] = c->timing[i];
+    return GZ_OK;
+}
+
+// ---- compact rows for the exchange step -----------------------------------------------------------------------------
+int gz_compact_rows(gz_ctx* c, const int32_t* rows_dev, const int32_t* n_real_dev, int64_t n_rows, int32_t row_len,
+                    int32_t* out_dev, int64_t* total_host)
+{
+    if (!c || !rows_dev || !n_real_dev || !out_dev || !total_host || n_rows < 0 || row_len <= 0)
+        return c ? fail(c, GZ_E_INVALID, "bad arguments") : GZ_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure(c, c->w_rowoff32, (size_t)(n_rows + 2) * 4))) return rc;
+    uint32_t* off = (uint32_t*)c->w_rowoff32.p;
+    gz_launch_row_offsets(n_real_dev, n_rows, off, c->stream);
+    gz_launch_compact(rows_dev, off, n_rows, row_len, out_dev, c->stream);
+    uint32_t total = 0;
+    HIPCHK(c, hipMemcpyAsync(&total, off + n_rows, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    *total_host = total;
+    return GZ_OK;
+}
+
+int gz_expand_rows(gz_ctx* c, const int32_t* compact_dev, const int32_t* n_real_dev, int64_t n_rows, int32_t row_len,
+                   int32_t* ids_dev, int32_t* mask_dev)
+{
+    if (!c || !compact_dev || !n_real_dev || !ids_dev || !mask_dev || n_rows < 0 || row_len <= 0)
+        return c ? fail(c, GZ_E_INVALID, "bad arguments") : GZ_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->have_tables) return fail(c, GZ_E_NOTABLES, "gz_load_tables has not been called");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure(c, c->w_rowoff32, (size_t)(n_rows + 2) * 4))) return rc;
+    uint32_t* off = (uint32_t*)c->w_rowoff32.p;
+    gz_launch_row_offsets(n_real_dev, n_rows, off, c->stream);
+    gz_launch_expand(compact_dev, off, n_rows, row_len, c->dev.pad_id, ids_dev, mask_dev, c->stream);
+    HIPCHK(c, hipGetLastError());
     return GZ_OK;
 }
 

@@ -167,6 +167,17 @@ int  gz_comm_init(gz_ctx *ctx, const uint8_t id[128], int rank, int world);
 int  gz_gather_rows(gz_ctx *ctx, const int32_t *send_dev, int64_t n_rows_local, int32_t row_len,
                     int32_t *recv_dev, const int64_t *rows_per_rank, int root);
 
+/* Compact form of dense rows for the exchange step: most of a [n_rows, row_len] block is padding, so a rank sends
+ * only the n_real[i] leading entries of every row (+ the counts) and the root re-creates padding and mask.
+ *   gz_compact_rows   rows_dev [n_rows,row_len] + n_real_dev [n_rows] -> out_dev (concatenated leading entries);
+ *                     *total_host = number of entries written (the call synchronises the context's stream)
+ *   gz_expand_rows    the inverse on the receiving side: compact_dev + n_real_dev -> ids_dev, mask_dev
+ *                     ([n_rows,row_len] each; padding = the pad id of the loaded tables, mask = id != pad) */
+int  gz_compact_rows(gz_ctx *ctx, const int32_t *rows_dev, const int32_t *n_real_dev, int64_t n_rows, int32_t row_len,
+                     int32_t *out_dev, int64_t *total_host);
+int  gz_expand_rows(gz_ctx *ctx, const int32_t *compact_dev, const int32_t *n_real_dev, int64_t n_rows, int32_t row_len,
+                    int32_t *ids_dev, int32_t *mask_dev);
+
 #ifdef __cplusplus
 }
 #endif

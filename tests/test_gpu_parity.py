@@ -265,3 +265,26 @@ def test_rccl_gather_rows_single_rank(tok):
     ctx.d2h(back, d_dst)
     assert np.array_equal(back, rows)
     ctx.free(d_src); ctx.free(d_dst)
+
+
+def test_compact_expand_round_trip(tok, sampler):
+    """The exchange step's compact form: rows without padding -> padding and mask rebuilt == the dense output."""
+    ctx = tok._ctx
+    text, offs, L = corpus.config_corpus(3, n_docs=5000, seed=31, sampler=sampler)
+    out = tok.encode_packed(text, offs, max_len=L)
+    ids, mask, n_real = out["input_ids"], out["attention_mask"], out["n_real"]
+    n = len(offs) - 1
+    d_ids = ctx.alloc(ids.nbytes); d_nr = ctx.alloc(n_real.nbytes); d_comp = ctx.alloc(ids.nbytes)
+    d_i2 = ctx.alloc(ids.nbytes); d_m2 = ctx.alloc(ids.nbytes)
+    ctx.h2d(d_ids, ids); ctx.h2d(d_nr, n_real)
+    total = ctx.compact_rows(d_ids, d_nr, n, L, d_comp)
+    assert total == int(n_real.sum())
+    comp = np.empty(total, dtype=np.int32); ctx.d2h(comp, d_comp)
+    assert np.array_equal(comp, np.concatenate([ids[i, :n_real[i]] for i in range(n)]))
+    ctx.expand_rows(d_comp, d_nr, n, L, d_i2, d_m2)
+    ctx.sync()
+    i2 = np.empty_like(ids); m2 = np.empty_like(mask)
+    ctx.d2h(i2, d_i2); ctx.d2h(m2, d_m2)
+    assert np.array_equal(i2, ids) and np.array_equal(m2, mask)
+    for p in (d_ids, d_nr, d_comp, d_i2, d_m2):
+        ctx.free(p)
