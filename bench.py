@@ -194,6 +194,27 @@ def main():
         ctx.encode_device(d_text, d_off, 0, 0, n, L, flags, n * L, d_ids, d_mask, d_n_real=d_nreal)
         ctx.sync()
 
+    # ---- secondary measurement: BASELINE configs[1] (10 k short sentences, max_len=128) -- the launch-latency regime
+    small = None
+    if world == 1 and not args.no_merge_only:
+        t2, o2, L2 = corpus.config_corpus(2)
+        n2 = len(o2) - 1
+        d_t2 = ctx.alloc(len(t2) + 64); ctx.h2d(d_t2, t2)
+        d_o2 = ctx.alloc(8 * (n2 + 1)); ctx.h2d(d_o2, o2)
+        d_i2 = ctx.alloc(4 * n2 * L2); d_m2 = ctx.alloc(4 * n2 * L2); d_r2 = ctx.alloc(4 * n2)
+        ms3 = []
+        for k in range(13):
+            t_a = time.perf_counter()
+            ctx.encode_device(d_t2, d_o2, 0, 0, n2, L2, flags, n2 * L2, d_i2, d_m2, d_n_real=d_r2)
+            ctx.sync()
+            ms3.append(((time.perf_counter() - t_a) * 1e3, ctx.timing()[0]))
+        wall = float(np.median([a for a, _ in ms3[3:]])); kern = float(np.median([b for _, b in ms3[3:]]))
+        small = {"workload": "BASELINE configs[1]: %d short sentences (%.2f MB), max_len=%d" % (n2, len(t2) / 1e6, L2),
+                 "ms_per_step_wall": round(wall, 4), "kernels_ms": round(kern, 4),
+                 "MB_per_s": round(len(t2) / wall / 1e3, 1)}
+        for q in (d_t2, d_o2, d_i2, d_m2, d_r2):
+            ctx.free(q)
+
     # ---- after the timed region: counts, verification, CPU baseline -------------------------------------------------
     n_real = np.empty(n, dtype=np.int32); ctx.d2h(n_real, d_nreal)
     tokens_local = int(n_real.sum())
@@ -269,6 +290,7 @@ def main():
                          "timed_with": "hipEvents on the library's stream around the step's launches"},
             "verified": verify,
             "merge_loop_only": merge_only,
+            "configs_1_small_batch": small,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(text, offs, L)
