@@ -219,6 +219,46 @@ def test_noisy_pairs_vs_oracle(tok, oracle_tables, sampler, shape):
         _compare_batch(out, want, True)
 
 
+def _gather(flat, off, lens):
+    """Concatenate flat[off[i] : off[i] + lens[i]] for all i."""
+    lens = np.asarray(lens, np.int64)
+    cum = np.concatenate([[0], np.cumsum(lens)])
+    return flat[np.repeat(np.asarray(off, np.int64) - cum[:-1], lens) + np.arange(cum[-1])]
+
+
+@pytest.mark.parametrize("shape", [(96, True, True), (None, True, True), (40, True, False), (3, True, True)])
+def test_large_noisy_vs_c_oracle(tok, sampler, shape):
+    """20 k noisy documents, single and paired, against the plain-C restatement (oracle/gz_oracle.c), compared as
+    whole arrays: ids, mask, row offsets, status, sequence_id and token_type_ids."""
+    import gz_oracle_c as OC
+    from corpus import VOCAB_PATH, BPE_PATH
+    co = OC.COracle(open(VOCAB_PATH, "rb").read(), open(BPE_PATH, "rb").read())
+    ml, pad, tr = shape
+    ta, oa, _ = corpus.config_corpus(3, n_docs=20000, seed=31, sampler=sampler)
+    tb, ob, _ = corpus.config_corpus(2, n_docs=20000, seed=32, sampler=sampler)
+    ta, oa = corpus.add_noise(ta, oa, seed=3, rate=0.04)
+    tb, ob = corpus.add_noise(tb, ob, seed=4, rate=0.04)
+    ta, tb = np.ascontiguousarray(ta), np.ascontiguousarray(tb)
+    oa, ob = np.ascontiguousarray(oa, dtype=np.int64), np.ascontiguousarray(ob, dtype=np.int64)
+    for pair in (False, True):
+        ids, mask, tt, sq, row, pl, st = co.call_packed(ta, oa, tb if pair else None, ob if pair else None, ml, pad, tr)
+        lens = np.diff(row)
+        for wt in (True, False):
+            out = (tok.encode_packed(ta, oa, tb, ob, max_len=ml, padding=pad, truncation=tr, word_table=wt) if pair else
+                   tok.encode_packed(ta, oa, max_len=ml, padding=pad, truncation=tr, word_table=wt))
+            ro = np.asarray(out["row_off"], np.int64)
+            assert np.array_equal(np.diff(ro), lens)
+            assert np.array_equal(_gather(out["input_ids"].reshape(-1), ro[:-1], lens), ids[:row[-1]])
+            assert np.array_equal(_gather(out["attention_mask"].reshape(-1), ro[:-1], lens), mask[:row[-1]])
+            if pair:
+                assert np.array_equal(np.asarray(out["status"]), st)
+                assert st.sum() > 0 or ml is None or ml > 8
+                gl = np.asarray(out["pair_len"]).reshape(-1, 2)
+                assert np.array_equal(gl, pl.reshape(-1, 2))
+                assert np.array_equal(_gather(out["sequence_id"].reshape(-1), ro[:-1], gl[:, 0]), _gather(sq, row[:-1], gl[:, 0]))
+                assert np.array_equal(_gather(out["token_type_ids"].reshape(-1), ro[:-1], gl[:, 1]), _gather(tt, row[:-1], gl[:, 1]))
+
+
 def test_long_and_huge_words(tok, oracle_tables):
     """Words of 17..1024 symbols take the wave-cooperative LDS path, longer ones the global arena pass; a word may
     also straddle or fill whole 1-KiB tiles."""
