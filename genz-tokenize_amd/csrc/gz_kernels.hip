@@ -31,6 +31,12 @@ __device__ __forceinline__ void nt_store4(int32_t* p, int32_t a, int32_t b, int3
     __builtin_nontemporal_store(v, reinterpret_cast<v4i*>(p));
 }
 __device__ __forceinline__ uint64_t lt_mask(int lane) { return (1ull << lane) - 1ull; }
+// ballot of a predicate (v_cmp straight into an SGPR pair) and "set bits of m below my lane" (v_mbcnt)
+__device__ __forceinline__ uint64_t wballot(bool p) { return __builtin_amdgcn_ballot_w64(p); }
+__device__ __forceinline__ int below(uint64_t m)
+{
+    return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+}
 
 __device__ __forceinline__ int wave_excl_sum(int v, int lane, int& total)
 {
@@ -192,8 +198,8 @@ __device__ __noinline__ int wave_merge(const GzDeviceTables* Tp, uint32_t* S, in
             const int i = base + lane;
             const uint32_t s = i < n ? S[i] : GZ_NO_SYMBOL;
             const uint32_t s1 = i + 1 < n ? S[i + 1] : GZ_NO_SYMBOL;
-            const uint64_t valid = __ballot(i < n);
-            uint64_t m = __ballot(i + 1 < n && s == mi.left && s1 == mi.right);
+            const uint64_t valid = wballot(i < n);
+            uint64_t m = wballot(i + 1 < n && s == mi.left && s1 == mi.right);
             if (skip0) m &= ~1ull;
             uint64_t pick = m;
             if (mi.left == mi.right) {                     // overlapping candidates: greedy left to right
@@ -208,7 +214,7 @@ __device__ __noinline__ int wave_merge(const GzDeviceTables* Tp, uint32_t* S, in
             const uint64_t keep = valid & ~((pick << 1) | (skip0 ? 1ull : 0ull));
             skip0 = (pick >> 63) & 1ull;
             const uint32_t val = ((pick >> lane) & 1ull) ? mi.merged : s;
-            const int dest = out + __popcll(keep & lt_mask(lane));
+            const int dest = out + below(keep);
             if ((keep >> lane) & 1ull) S[dest] = val;
             out += __popcll(keep);
         }
@@ -238,11 +244,11 @@ __device__ __noinline__ int long_word(const GzDeviceTables* Tp, uint32_t* lds_sc
     for (int64_t base = 0; base < nbytes; base += WAVE) {
         const int64_t i = base + lane;
         const bool lead = i < nbytes && (g[i] & 0xC0) != 0x80;
-        const uint64_t m = __ballot(lead);
+        const uint64_t m = wballot(lead);
         if (lead) {
             int len;
             const uint32_t cp = decode_cp(at, i, nbytes, len);
-            const int idx = symbase + __popcll(m & lt_mask(lane));
+            const int idx = symbase + below(m);
             S[idx] = initial_symbol(T, cp, !glue && idx == n - 1);
         }
         symbase += __popcll(m);
@@ -384,7 +390,7 @@ __global__ __launch_bounds__(WAVE * WPB) void gz_pair_kernel(GzDeviceTables T, G
     int p1 = R;
     for (int base = 0; base < R; base += WAVE) {
         const int i = base + lane;
-        const uint64_t m = __ballot(i < R && ids[i] == eos);
+        const uint64_t m = wballot(i < R && ids[i] == eos);
         if (m) { p1 = base + __ffsll((unsigned long long)m) - 1; break; }
     }
     // p2: first eos after p1 that directly follows a `1` entry (:176-179) -> the list ends there
@@ -392,7 +398,7 @@ __global__ __launch_bounds__(WAVE * WPB) void gz_pair_kernel(GzDeviceTables T, G
     for (int base = (p1 + 2) & ~(WAVE - 1); base < R; base += WAVE) {
         const int i = base + lane;
         const bool hit = i < R && i >= p1 + 2 && ids[i] == eos && ids[i - 1] != eos;
-        const uint64_t m = __ballot(hit);
+        const uint64_t m = wballot(hit);
         if (m) { seq_len = base + __ffsll((unsigned long long)m) - 1 + 1; break; }
     }
     auto raw_val = [&](int i) -> int32_t {                     // the list before get_token_type touches it
@@ -406,7 +412,7 @@ __global__ __launch_bounds__(WAVE * WPB) void gz_pair_kernel(GzDeviceTables T, G
     for (int base = 0; base < seq_len && n2 < 0; base += WAVE) {
         const int i = base + lane;
         const bool none = i > 0 && i < seq_len - 1 && raw_val(i) == GZ_NONE_;
-        uint64_t m = __ballot(none);
+        uint64_t m = wballot(none);
         while (m && n2 < 0) {
             const int p = base + __ffsll((unsigned long long)m) - 1;
             if (n1 < 0) n1 = p; else n2 = p;

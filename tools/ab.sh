@@ -1,0 +1,19 @@
+#!/bin/bash
+# usage (GPU box, repo root): tools/ab.sh <libA.so> <libB.so> ...   -- A/B the pipeline kernels of several builds on
+# the SAME box (boxes differ by a few percent): each build is copied over the in-tree library and traced twice.
+set -o pipefail
+R=$PWD
+LIB=$R/genz-tokenize_amd/genz_tokenize/libgenz_tokenize_hip.so
+cp $LIB /tmp/orig.so
+cd /tmp && export TMPDIR=/tmp
+for rep in 1 2; do
+  for so in "$@"; do
+    tag=$(basename $so .so)_$rep
+    cp $R/$so $LIB
+    rm -rf /tmp/prof_$tag
+    timeout -k 10 300 rocprofv3 --kernel-trace -d /tmp/prof_$tag -o t --output-format csv -- python3 $R/tools/prof_run.py ${NDOCS:-1000000} 5 > /tmp/prof_$tag.log 2>&1 || { tail -20 /tmp/prof_$tag.log; cp /tmp/orig.so $LIB; exit 1; }
+    echo "== $tag: $(grep '^docs' /tmp/prof_$tag.log | sed 's/.*kernel ms//')"
+    python3 $R/tools/trace_summary.py /tmp/prof_$tag | grep -E "classify|words_k|miss_k|miss_wide|assemble|sum of" | awk '{printf "%s %s | ", $1, $(NF-1)} END {print ""}'
+  done
+done
+cp /tmp/orig.so $LIB

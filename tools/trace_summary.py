@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-kernel durations of the steady-state launches in a rocprofv3 --kernel-trace CSV (last 3 launches of each)."""
 import collections, csv, glob, sys
-f = glob.glob(sys.argv[1] + '/*/*kernel_trace.csv')[0]
+f = (glob.glob(sys.argv[1] + '/*/*kernel_trace.csv') + glob.glob(sys.argv[1] + '/*kernel_trace.csv'))[0]
 by = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
     if r['Kernel_Name'].startswith('gz_'):
