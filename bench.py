@@ -242,6 +242,28 @@ def main():
 
     # ---- after the timed region: counts, verification, CPU baseline -------------------------------------------------
     n_real = np.empty(n, dtype=np.int32); ctx.d2h(n_real, d_nreal)
+    decode_info = None
+    if world == 1 and rank == 0 and not args.no_merge_only:
+        # secondary: batch decode of the step's real tokens, ids resident in HBM
+        roff = np.zeros(n + 1, dtype=np.int64); np.cumsum(n_real, out=roff[1:])
+        nt = int(roff[-1])
+        d_c = ctx.alloc(4 * nt + 64); ctx.compact_rows(d_ids, d_nreal, n, L, d_c)
+        d_ro = ctx.alloc(8 * (n + 1)); ctx.h2d(d_ro, roff)
+        d_oo = ctx.alloc(8 * (n + 1))
+        unk = tok.unk_token.encode()
+        need = ctx.decode_device(d_c, d_ro, n, unk, 0, 0, d_oo)
+        d_txt = ctx.alloc(need + 64)
+        dts = []
+        for _ in range(4):
+            t_a = time.perf_counter()
+            ctx.decode_device(d_c, d_ro, n, unk, d_txt, need, d_oo)
+            dts.append(time.perf_counter() - t_a)
+        dt = min(dts[1:])
+        decode_info = {"workload": "decode_batch of the step's %d real tokens (%d rows), ids and text resident in HBM" % (nt, n),
+                       "ms": round(dt * 1e3, 3), "tokens_per_s": round(nt / dt, 1), "text_MB_per_s": round(need / dt / 1e6, 1),
+                       "text_bytes": int(need)}
+        for q in (d_c, d_ro, d_oo, d_txt):
+            ctx.free(q)
     tokens_local = int(n_real.sum())
     tot = np.array([in_bytes, tokens_local, n], dtype=np.float64)
     if dist is not None:
@@ -316,6 +338,7 @@ def main():
             "verified": verify,
             "merge_loop_only": merge_only,
             "configs_1_small_batch": small,
+            "decode_batch": decode_info,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(text, offs, L)

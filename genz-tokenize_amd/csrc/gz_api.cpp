@@ -99,6 +99,13 @@ struct gz_ctx {
     DBuf w_pick, w_rowoff32;
     int64_t* h_pick = nullptr;           // pinned
     int64_t n_words = 0;
+    // decoder snapshot + decode workspace
+    bool have_dec = false;
+    int32_t dec_n_ids = 0;
+    size_t dec_bytes_len = 0;
+    std::string dec_unk;
+    bool dec_unk_set = false;
+    DBuf t_dec_entries, t_dec_bytes, w_dec_ids, w_dec_roff, w_dec_rb, w_dec_ooff, w_dec_out;
     bool building_words = false;         // the whole-word table is being built: ignore diagnostics
     bool no_words_env = false;           // GZ_WORD_TABLE=0 in the environment
 };
@@ -475,6 +482,7 @@ void gz_destroy(gz_ctx* c)
     if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->h_pick) hipHostFree(c->h_pick);
     release(c->w_pick); release(c->w_rowoff32);
+    for (DBuf* b : {&c->t_dec_entries, &c->t_dec_bytes, &c->w_dec_ids, &c->w_dec_roff, &c->w_dec_rb, &c->w_dec_ooff, &c->w_dec_out}) release(*b);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     for (DBuf* b : {&c->t_pair, &c->t_merges, &c->t_symids, &c->t_bmp, &c->t_astral, &c->t_struct, &c->t_words2, &c->t_words0, &c->w_text, &c->w_toff, &c->w_pair,
                     &c->w_poff, &c->w_ids, &c->w_mask, &c->w_tt, &c->w_seq, &c->w_rowoff, &c->w_rowlen, &c->w_pairlen,
@@ -797,6 +805,131 @@ int gz_timing(gz_ctx* c, double out_ms[4])
 {
     if (!c || !out_ms) return GZ_E_INVALID;
     for (int i = 0; i < 4; ++i) out_ms[i] = c->timing[i];
+    return GZ_OK;
+}
+
+// ---- batch decode ----------------------------------------------------------------------------------------------------
+namespace {
+constexpr size_t GZ_DEC_UNK_MAX = 4096;
+
+uint32_t dec_flags(const std::string& w)
+{
+    uint32_t f = (uint32_t)w.size();
+    if (w.size() >= 2 && w[w.size() - 1] == '@' && w[w.size() - 2] == '@') f |= GZ_DEC_ENDS_ATAT;
+    if (w.find("@@ ") != std::string::npos) f |= GZ_DEC_INNER;
+    return f;
+}
+
+int dec_set_unk(gz_ctx* c, const uint8_t* unk, int32_t unk_len)
+{
+    if (unk_len < 0 || (size_t)unk_len > GZ_DEC_UNK_MAX) return fail(c, GZ_E_LIMIT, "unk string longer than %zu bytes", GZ_DEC_UNK_MAX);
+    const std::string u((const char*)unk, (size_t)unk_len);
+    if (c->dec_unk_set && u == c->dec_unk) return GZ_OK;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (unk_len) HIPCHK(c, hipMemcpy((uint8_t*)c->t_dec_bytes.p + c->dec_bytes_len, unk, (size_t)unk_len, hipMemcpyHostToDevice));
+    GzDecEntry e{(uint32_t)c->dec_bytes_len, dec_flags(u)};
+    HIPCHK(c, hipMemcpy((GzDecEntry*)c->t_dec_entries.p + c->dec_n_ids, &e, sizeof e, hipMemcpyHostToDevice));
+    c->dec_unk = u;
+    c->dec_unk_set = true;
+    return GZ_OK;
+}
+
+// both passes; *total = bytes of the whole batch.  out_dev may be nullptr (sizes only).
+int decode_device_locked(gz_ctx* c, const int32_t* ids_dev, const int64_t* row_off_dev, int64_t n_rows, const uint8_t* unk,
+                         int32_t unk_len, uint8_t* out_dev, int64_t capacity, int64_t* out_off_dev, int64_t* total)
+{
+    if (!c->have_dec) return fail(c, GZ_E_NOTABLES, "gz_decoder_snapshot has not been called");
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = dec_set_unk(c, unk, unk_len))) return rc;
+    if ((rc = ensure(c, c->w_dec_rb, (size_t)(n_rows + 1) * 8))) return rc;
+    GzDecTable D{(const GzDecEntry*)c->t_dec_entries.p, (const uint8_t*)c->t_dec_bytes.p, c->dec_n_ids};
+    gz_launch_decode(D, ids_dev, row_off_dev, n_rows, (int64_t*)c->w_dec_rb.p, out_off_dev, nullptr, 0, c->stream);
+    *total = 0;
+    if (n_rows > 0) HIPCHK(c, hipMemcpyAsync(total, out_off_dev + n_rows, 8, hipMemcpyDeviceToHost, c->stream));
+    else HIPCHK(c, hipMemsetAsync(out_off_dev, 0, 8, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!out_dev) return GZ_OK;
+    if (*total > capacity) return fail(c, GZ_E_CAPACITY, "decode needs %lld bytes, capacity is %lld", (long long)*total, (long long)capacity);
+    gz_launch_decode(D, ids_dev, row_off_dev, n_rows, nullptr, out_off_dev, out_dev, capacity, c->stream);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    return GZ_OK;
+}
+}  // namespace
+
+int gz_decoder_snapshot(gz_ctx* c)
+{
+    if (!c) return GZ_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->have_tables) return fail(c, GZ_E_NOTABLES, "gz_load_tables has not been called");
+    HIPCHK(c, hipSetDevice(c->device));
+    // {v: k for k, v in encoder.items()} (tokenize.py:40): the last word wins on an id collision
+    int32_t n_ids = 0;
+    for (int32_t id : c->host.enc_ids) if (id + 1 > n_ids) n_ids = id + 1;
+    std::vector<int64_t> last((size_t)n_ids, -1);
+    for (size_t i = 0; i < c->host.enc_ids.size(); ++i) if (c->host.enc_ids[i] >= 0) last[(size_t)c->host.enc_ids[i]] = (int64_t)i;
+    std::vector<GzDecEntry> ent((size_t)n_ids + 1, GzDecEntry{0, GZ_DEC_ABSENT});
+    std::string bytes;
+    for (int32_t id = 0; id < n_ids; ++id) {
+        if (last[(size_t)id] < 0) continue;
+        const std::string& w = c->host.enc_words[(size_t)last[(size_t)id]];
+        if (w.size() > GZ_DEC_LEN_MASK || bytes.size() + w.size() > 0xFFFF0000ull) return fail(c, GZ_E_LIMIT, "vocabulary too large for the decoder arena");
+        ent[(size_t)id] = GzDecEntry{(uint32_t)bytes.size(), dec_flags(w)};
+        bytes += w;
+    }
+    ent[(size_t)n_ids] = GzDecEntry{(uint32_t)bytes.size(), 0};
+    int rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if ((rc = ensure(c, c->t_dec_entries, ent.size() * sizeof(GzDecEntry)))) return rc;
+    if ((rc = ensure(c, c->t_dec_bytes, bytes.size() + GZ_DEC_UNK_MAX + 16))) return rc;
+    HIPCHK(c, hipMemcpy(c->t_dec_entries.p, ent.data(), ent.size() * sizeof(GzDecEntry), hipMemcpyHostToDevice));
+    if (!bytes.empty()) HIPCHK(c, hipMemcpy(c->t_dec_bytes.p, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
+    c->dec_n_ids = n_ids;
+    c->dec_bytes_len = bytes.size();
+    c->dec_unk_set = false;
+    c->have_dec = true;
+    return GZ_OK;
+}
+
+int gz_decode_batch_device(gz_ctx* c, const int32_t* ids_dev, const int64_t* row_off_dev, int64_t n_rows, const uint8_t* unk,
+                           int32_t unk_len, uint8_t* out_dev, int64_t capacity, int64_t* out_off_dev, int64_t* total_host)
+{
+    if (!c || !row_off_dev || !out_off_dev || !total_host || n_rows < 0 || (!unk && unk_len) || capacity < 0)
+        return c ? fail(c, GZ_E_INVALID, "bad arguments") : GZ_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mu);
+    return decode_device_locked(c, ids_dev, row_off_dev, n_rows, unk, unk_len, out_dev, capacity, out_off_dev, total_host);
+}
+
+int gz_decode_batch(gz_ctx* c, const int32_t* ids, const int64_t* row_off, int64_t n_rows, const uint8_t* unk, int32_t unk_len,
+                    uint8_t* out, int64_t capacity, int64_t* out_off)
+{
+    if (!c || !row_off || !out_off || n_rows < 0 || (!unk && unk_len) || capacity < 0 || (capacity > 0 && !out))
+        return c ? fail(c, GZ_E_INVALID, "bad arguments") : GZ_E_INVALID;
+    const int64_t n_ids = row_off[n_rows] - row_off[0];
+    if (n_ids < 0 || (n_ids > 0 && !ids)) return fail(c, GZ_E_INVALID, "bad row offsets");
+    for (int64_t r = 0; r < n_rows; ++r) if (row_off[r + 1] < row_off[r]) return fail(c, GZ_E_INVALID, "row offsets must not decrease");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure(c, c->w_dec_ids, (size_t)(n_ids + 1) * 4))) return rc;
+    if ((rc = ensure(c, c->w_dec_roff, (size_t)(n_rows + 1) * 8))) return rc;
+    if ((rc = ensure(c, c->w_dec_ooff, (size_t)(n_rows + 1) * 8))) return rc;
+    if (n_ids) HIPCHK(c, hipMemcpyAsync(c->w_dec_ids.p, ids + row_off[0], (size_t)n_ids * 4, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->w_dec_roff.p, row_off, (size_t)(n_rows + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    int64_t total = 0;
+    if ((rc = decode_device_locked(c, (const int32_t*)c->w_dec_ids.p, (const int64_t*)c->w_dec_roff.p, n_rows, unk, unk_len, nullptr, 0,
+                                   (int64_t*)c->w_dec_ooff.p, &total))) return rc;
+    HIPCHK(c, hipMemcpy(out_off, c->w_dec_ooff.p, (size_t)(n_rows + 1) * 8, hipMemcpyDeviceToHost));
+    if (total > capacity) return fail(c, GZ_E_CAPACITY, "decode needs %lld bytes, capacity is %lld", (long long)total, (long long)capacity);
+    if (total == 0) return GZ_OK;
+    if ((rc = ensure(c, c->w_dec_out, (size_t)total))) return rc;
+    GzDecTable D{(const GzDecEntry*)c->t_dec_entries.p, (const uint8_t*)c->t_dec_bytes.p, c->dec_n_ids};
+    gz_launch_decode(D, (const int32_t*)c->w_dec_ids.p, (const int64_t*)c->w_dec_roff.p, n_rows, nullptr, (int64_t*)c->w_dec_ooff.p,
+                     (uint8_t*)c->w_dec_out.p, total, c->stream);
+    HIPCHK(c, hipMemcpyAsync(out, c->w_dec_out.p, (size_t)total, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
     return GZ_OK;
 }
 

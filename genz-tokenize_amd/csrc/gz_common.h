@@ -87,6 +87,18 @@ struct GzDeviceTables {
 };
 
 // Host-side result of the loader (tokenize.py:31-57) and of the table build.
+// ---- decoder snapshot (id -> word bytes), tokenize.py:40 -------------------------------------------------------------
+struct GzDecEntry { uint32_t off; uint32_t len_flags; };       // len:24 | flags
+constexpr uint32_t GZ_DEC_LEN_MASK  = 0x00FFFFFFu;
+constexpr uint32_t GZ_DEC_ENDS_ATAT = 0x01000000u;              // the word ends in "@@"
+constexpr uint32_t GZ_DEC_INNER     = 0x02000000u;              // the word contains "@@ " inside: filter byte by byte
+constexpr uint32_t GZ_DEC_ABSENT    = 0xFFFFFFFFu;              // no word has this id
+struct GzDecTable {
+    const GzDecEntry* entries;      // [n_ids + 1]; entries[n_ids] = the unk string of the current call
+    const uint8_t*    bytes;
+    int32_t           n_ids;
+};
+
 struct GzHostTables {
     // encoder in insertion order (Python dict order): word bytes, id (ids can repeat: rule L3)
     std::vector<std::string> enc_words;

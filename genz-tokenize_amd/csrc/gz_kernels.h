@@ -75,3 +75,6 @@ void gz_launch_finalize(const GzDeviceTables& T, const GzFinalizeArgs& F, hipStr
 void gz_launch_pair(const GzDeviceTables& T, const GzPairArgs& P, hipStream_t s);
 void gz_launch_bpe_word(const GzDeviceTables* T_dev, const uint8_t* word, int64_t nbytes, uint32_t* arena,
                         int32_t* out, int32_t cap, int32_t* n_out, hipStream_t s);
+// batch decode: out == nullptr -> row_bytes[n_rows] + out_off[n_rows + 1] (exclusive scan); else write the text
+void gz_launch_decode(const GzDecTable& D, const int32_t* ids, const int64_t* row_off, int64_t n_rows, int64_t* row_bytes,
+                      int64_t* out_off, uint8_t* out, int64_t capacity, hipStream_t s);

@@ -477,6 +477,7 @@ void gz_launch_pick(const int64_t* off, const int64_t* off2, int64_t n_docs, int
 }
 
 #include "gz_pipeline.inc"
+#include "gz_decode.inc"
 
 // =================================================================================================================
 // launchers
@@ -505,4 +506,19 @@ void gz_launch_bpe_word(const GzDeviceTables* T, const uint8_t* word, int64_t nb
                         int32_t* out, int32_t cap, int32_t* n_out, hipStream_t s)
 {
     hipLaunchKernelGGL(gz_bpe_word_kernel, dim3(1), dim3(WAVE), 0, s, T, word, nbytes, arena, out, cap, n_out);
+}
+
+void gz_launch_decode(const GzDecTable& D, const int32_t* ids, const int64_t* row_off, int64_t n_rows, int64_t* row_bytes,
+                      int64_t* out_off, uint8_t* out, int64_t capacity, hipStream_t s)
+{
+    if (n_rows <= 0) return;
+    const unsigned grid = (unsigned)((n_rows + 3) / 4);
+    if (!out) {
+        hipLaunchKernelGGL(gz_decode_kernel, dim3(grid), dim3(WAVE * 4), 0, s, D, ids, row_off, n_rows, row_bytes,
+                           (const int64_t*)nullptr, (uint8_t*)nullptr, (int64_t)0);
+        hipLaunchKernelGGL(gz_scan_kernel, dim3(1), dim3(1024), 0, s, (const int64_t*)row_bytes, n_rows, out_off);
+    } else {
+        hipLaunchKernelGGL(gz_decode_kernel, dim3(grid), dim3(WAVE * 4), 0, s, D, ids, row_off, n_rows, (int64_t*)nullptr,
+                           (const int64_t*)out_off, out, capacity);
+    }
 }

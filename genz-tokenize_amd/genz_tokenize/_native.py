@@ -24,7 +24,7 @@ SYMBOLS = [
     "gz_version", "gz_create", "gz_destroy", "gz_last_error", "gz_load_tables", "gz_table_info",
     "gz_vocab_entry", "gz_merge_entry", "gz_encode_batch", "gz_encode_batch_device", "gz_sync",
     "gz_word_token_counts", "gz_bpe_word", "gz_symbol_utf8", "gz_device_alloc", "gz_device_free", "gz_memcpy_h2d", "gz_memcpy_d2h",
-    "gz_timing", "gz_comm_unique_id", "gz_comm_init", "gz_gather_rows", "gz_compact_rows", "gz_expand_rows",
+    "gz_timing", "gz_decoder_snapshot", "gz_decode_batch", "gz_decode_batch_device", "gz_comm_unique_id", "gz_comm_init", "gz_gather_rows", "gz_compact_rows", "gz_expand_rows",
     "gz_host_tables_create", "gz_host_tables_destroy", "gz_host_tables_array", "gz_host_tables_vocab_entry",
     "gz_host_tables_merge_entry", "gz_host_tables_symbol",
 ]
@@ -70,6 +70,9 @@ def load_library():
     L.gz_memcpy_h2d.argtypes = [vp, vp, vp, sz]
     L.gz_memcpy_d2h.argtypes = [vp, vp, vp, sz]
     L.gz_timing.argtypes = [vp, P(C.c_double)]
+    L.gz_decoder_snapshot.argtypes = [vp]
+    L.gz_decode_batch.argtypes = [vp, vp, vp, i64, vp, i32, vp, i64, vp]
+    L.gz_decode_batch_device.argtypes = [vp, vp, vp, i64, vp, i32, vp, i64, vp, P(i64)]
     L.gz_comm_unique_id.argtypes = [vp]
     L.gz_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
     L.gz_gather_rows.argtypes = [vp, vp, i64, i32, vp, vp, C.c_int]
@@ -278,6 +281,36 @@ class Context:
     def comm_init(self, uid: bytes, rank: int, world: int):
         buf = C.create_string_buffer(uid, 128)
         self._check(self.lib.gz_comm_init(self.handle, C.cast(buf, C.c_void_p), rank, world))
+
+    # ---- batch decode -----------------------------------------------------------------------------------
+    def decoder_snapshot(self):
+        self._check(self.lib.gz_decoder_snapshot(self.handle))
+
+    def decode(self, ids: np.ndarray, row_off: np.ndarray, unk: bytes):
+        """ids int32 (packed rows), row_off int64 [n+1]  ->  (bytes of all rows, out_off int64 [n+1])."""
+        ids = np.ascontiguousarray(ids, dtype=np.int32)
+        row_off = np.ascontiguousarray(row_off, dtype=np.int64)
+        n = len(row_off) - 1
+        out_off = np.zeros(n + 1, dtype=np.int64)
+        ub = C.create_string_buffer(unk, len(unk))
+        cap = max(64, 6 * len(ids))
+        for _ in range(2):
+            out = np.empty(cap, dtype=np.uint8)
+            rc = self.lib.gz_decode_batch(self.handle, _ptr(ids) if len(ids) else None, _ptr(row_off), n,
+                                          C.cast(ub, C.c_void_p), len(unk), _ptr(out), cap, _ptr(out_off))
+            if rc != GZ_E_CAPACITY:
+                break
+            cap = int(out_off[n])
+        self._check(rc)
+        return out[:int(out_off[n])], out_off
+
+    def decode_device(self, d_ids, d_row_off, n_rows, unk: bytes, d_out, capacity, d_out_off) -> int:
+        total = C.c_int64()
+        ub = C.create_string_buffer(unk, len(unk))
+        self._check(self.lib.gz_decode_batch_device(self.handle, C.c_void_p(d_ids), C.c_void_p(d_row_off), n_rows,
+                                                    C.cast(ub, C.c_void_p), len(unk), C.c_void_p(d_out) if d_out else None,
+                                                    capacity, C.c_void_p(d_out_off), C.byref(total)))
+        return total.value
 
     def compact_rows(self, d_rows, d_n_real, n_rows, row_len, d_out) -> int:
         total = C.c_int64()

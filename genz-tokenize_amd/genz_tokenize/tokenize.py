@@ -71,6 +71,7 @@ class Tokenize(object):
         self._decoder_snapshot = None           # tokenize.py:40: decoder is built once, after the first vocab load
         self._sync_tables()
         self._decoder_snapshot = {v: k for k, v in self.encoder.items()}
+        self._ctx.decoder_snapshot()            # the same snapshot on the device (decode_batch)
         self.add_bpe_file(self.bpe_file)
 
     # ---- tables -------------------------------------------------------------------------------------------
@@ -176,6 +177,29 @@ class Tokenize(object):
         """tokenize.py:137-139 (host side: string assembly)."""
         dec, unk = self.decoder, self.unk_token
         return ' '.join(dec.get(i, unk) for i in token).replace('@@ ', '')
+
+    def decode_batch(self, rows) -> List[str]:
+        """`decode` for many id lists at once, on the GPU (the reference has no batch form).
+        `rows` is a sequence of integer sequences or a 2-D integer array; ids outside the int32 range decode to the
+        unk token like any other unknown id."""
+        if isinstance(rows, np.ndarray) and rows.ndim == 2:
+            n, L = rows.shape
+            flat = rows.reshape(-1)
+            off = np.arange(n + 1, dtype=np.int64) * L
+        else:
+            rows = [np.asarray(r, dtype=np.int64).reshape(-1) for r in rows]
+            off = np.zeros(len(rows) + 1, dtype=np.int64)
+            if rows:
+                np.cumsum([len(r) for r in rows], out=off[1:])
+            flat = np.concatenate(rows) if rows else np.zeros(0, dtype=np.int64)
+        flat = np.asarray(flat)
+        if flat.dtype != np.int32:
+            if flat.dtype.kind not in "iu":
+                raise TypeError("decode_batch() expects integer ids")
+            flat = np.where((flat < -(2 ** 31)) | (flat >= 2 ** 31), -1, flat).astype(np.int32)
+        data, out_off = self._ctx.decode(flat, off, self.unk_token.encode("utf-8", "surrogatepass"))
+        raw = data.tobytes()
+        return [raw[out_off[i]:out_off[i + 1]].decode("utf-8", "surrogatepass") for i in range(len(off) - 1)]
 
     def get_atttention_mask(self, token):
         pad = self._special_ids()[0]

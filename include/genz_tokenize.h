@@ -159,6 +159,24 @@ int  gz_host_tables_vocab_entry(gz_host_tables *t, int64_t i, const uint8_t **ut
 int  gz_host_tables_merge_entry(gz_host_tables *t, int64_t i, const uint8_t **utf8, int32_t *len, int32_t *n_fields, int32_t *rank);
 int  gz_host_tables_symbol(gz_host_tables *t, int32_t symbol, const uint8_t **utf8, int32_t *len);
 
+/* ---- batch decode ------------------------------------------------------------------------
+ * gz_decoder_snapshot: build the id -> word map from the tables loaded so far, the way the reference builds
+ *   `decoder` ONCE in __init__ (tokenize.py:40: {v: k for k, v in encoder.items()} -- on an id collision the last
+ *   word wins).  Later gz_load_tables calls do not change the snapshot.
+ * gz_decode_batch: Tokenize.decode (tokenize.py:137-139) + __convert_token_to_string (:123-124) for n_rows id lists:
+ *     ' '.join(decoder.get(i, unk) for i in row).replace('@@ ', '')
+ *   ids      int32, rows packed back to back; row r = ids[row_off[r] .. row_off[r+1])
+ *   unk      the caller's unk_token string (the reference reads self.unk_token at call time)
+ *   out      UTF-8 bytes of all rows back to back; out_off[n_rows+1] their byte offsets
+ *   Returns GZ_E_CAPACITY when `capacity` is too small; out_off is valid then (out_off[n_rows] = bytes needed).
+ * gz_decode_batch_device: the same with ids / row_off / out / out_off resident in HBM (total_host = bytes needed or
+ *   written); out_dev may be NULL to size the output only. */
+int  gz_decoder_snapshot(gz_ctx *ctx);
+int  gz_decode_batch(gz_ctx *ctx, const int32_t *ids, const int64_t *row_off, int64_t n_rows, const uint8_t *unk, int32_t unk_len,
+                     uint8_t *out, int64_t capacity, int64_t *out_off);
+int  gz_decode_batch_device(gz_ctx *ctx, const int32_t *ids_dev, const int64_t *row_off_dev, int64_t n_rows, const uint8_t *unk,
+                            int32_t unk_len, uint8_t *out_dev, int64_t capacity, int64_t *out_off_dev, int64_t *total_host);
+
 /* Multi-GPU exchange step (one process per GPU, RCCL over xGMI).  rank 0 creates an id, every rank calls
  * gz_comm_init with it; gz_gather_rows sends each rank's [n_rows, row_len] int32 device block to `root`,
  * which receives them back to back in rank order (grouped ncclSend/ncclRecv: each peer uses its own link). */

@@ -14,6 +14,9 @@ fixtures written here are data only (inputs + the reference's outputs):
                       every max_len / padding / truncation combination, exceptions recorded
   g4_loader.jsonl     Tokenize.fromFile on tiny synthetic tables exercising loader rules
                       L1-L7 (file bytes are stored in the fixture, base64)
+  g6_decode.jsonl     Tokenize.decode on seeded random id lists (bundled tables, ids of '@@' pieces at the end of a
+                      row, out-of-range / negative ids, a non-default unk_token) and on tiny tables whose words
+                      contain spaces, '@@ ' and empty strings (file bytes stored base64)
   g5_hashes.json      SHA-256 of the reference's input_ids/attention_mask over the seeded
                       synthetic corpora of corpus.py (corpora are re-generated from seed)
 """
@@ -290,11 +293,56 @@ def g5(full_cfg3: bool):
     json.dump(out, open(path, "w"), indent=1)
 
 
+# ------------------------------------------------------------------ G6
+def g6(tok):
+    r = random.Random(606)
+    n = tok.vocab_size()
+    cont = [i for w, i in tok.encoder.items() if w.endswith("@@")]
+    rows = []
+
+    def rand_ids():
+        k = r.choice([0, 1, 2, 3, 5, 8, 13, 40, 100])
+        out = []
+        for _ in range(k):
+            m = r.random()
+            if m < 0.45: out.append(r.randrange(n))
+            elif m < 0.75: out.append(r.choice(cont))
+            elif m < 0.85: out.append(r.randrange(5))
+            elif m < 0.92: out.append(r.choice([-1, -7, n, n + 1, n + 12345, 2 ** 31 - 1, -2 ** 31, 2 ** 40]))
+            else: out.append(r.choice(cont))
+        return out
+    bundled = [rand_ids() for _ in range(400)]
+    bundled += [[1, 770, 2], [], [cont[0]], [cont[0], cont[1]], [cont[0], cont[1], 5], [n], [-1]]
+    rows.append({"name": "bundled", "unk_token": "<unk>", "ids": bundled, "result": [tok.decode(x) for x in bundled]})
+    tok2 = Tokenize(unk_token="[không rõ]@@")
+    rows.append({"name": "bundled_custom_unk", "unk_token": "[không rõ]@@", "ids": bundled[:120],
+                 "result": [tok2.decode(x) for x in bundled[:120]]})
+    tables = {
+        "spaces_inside": "a@@ b 1\nx 1\n@@ 1\n@@@ 1\n@ 1\n\nq@@ @@ 3\n@@  z 1\ny@@ 1\n",
+        "dup_ids": "a 1\nb 1\na 2\nc@@ 1\nd 1\nc@@ 9\ne 1\n",
+        "special_in_vocab": "<unk> 1\na@@ 1\n</s> 1\nb 1\n<pad> 5\n",
+    }
+    tmp = tempfile.mkdtemp()
+    for name, v in tables.items():
+        vb, bb = v.encode("utf-8"), b"#v\n"
+        vp, bp = os.path.join(tmp, name + ".vocab"), os.path.join(tmp, name + ".bpe")
+        open(vp, "wb").write(vb); open(bp, "wb").write(bb)
+        t = Tokenize.fromFile(vp, bp)
+        m = t.vocab_size()
+        lists = [[r.randrange(-1, m + 2) for _ in range(r.choice([0, 1, 2, 3, 4, 6, 9, 17]))] for _ in range(150)]
+        lists += [list(range(m)), list(range(m - 1, -1, -1)), [i for i in range(m) for _ in range(2)]]
+        rows.append({"name": name, "vocab_b64": base64.b64encode(vb).decode(), "bpe_b64": base64.b64encode(bb).decode(),
+                     "unk_token": "<unk>", "decoder": sorted(t.decoder.items()), "ids": lists,
+                     "result": [t.decode(x) for x in lists]})
+    jl("g6_decode.jsonl", rows)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g3", "g4", "g5"]
+    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6"]
     tok = Tokenize()
     if "g1" in which: g1(tok)
     if "g3" in which: g3(tok)
     if "g4" in which: g4()
     if "g5" in which: g5(False)
     if "g5full" in which: g5(True)
+    if "g6" in which: g6(tok)

@@ -328,3 +328,47 @@ def test_compact_expand_round_trip(tok, sampler):
     assert np.array_equal(i2, ids) and np.array_equal(m2, mask)
     for p in (d_ids, d_nr, d_comp, d_i2, d_m2):
         ctx.free(p)
+
+
+def test_g6_decode_batch(tok, tmp_path):
+    """decode_batch (GPU) against the reference's decode outputs: '@@ ' joining, unknown ids, custom unk, tables whose
+    words contain spaces / '@@ ' / nothing at all, id collisions."""
+    import base64
+    from genz_tokenize import Tokenize
+    for row in read_jsonl("g6_decode.jsonl"):
+        if "vocab_b64" in row:
+            (tmp_path / "v").write_bytes(base64.b64decode(row["vocab_b64"]))
+            (tmp_path / "b").write_bytes(base64.b64decode(row["bpe_b64"]))
+            t = Tokenize.fromFile(str(tmp_path / "v"), str(tmp_path / "b"))
+        elif row["unk_token"] != "<unk>":
+            t = Tokenize(unk_token=row["unk_token"])
+        else:
+            t = tok
+        assert t.decode_batch(row["ids"]) == row["result"], row["name"]
+        for ids, want in list(zip(row["ids"], row["result"]))[:40]:
+            assert t.decode(ids) == want                      # the single-call form (host dict, like the reference)
+            assert t.decode_batch([ids]) == [want]
+    assert tok.decode_batch([]) == []
+    assert tok.decode_batch([[], []]) == ["", ""]
+
+
+def test_encode_decode_round_trip(tok, oracle_tables, sampler):
+    """20 k documents: encode on the GPU, decode the dense [N, L] id matrix on the GPU, compare every row with the
+    oracle's decode of the same ids; for documents without unknown pieces the text comes back word for word."""
+    text, offs, L = corpus.config_corpus(3, n_docs=20000, seed=41, sampler=sampler)
+    out = tok.encode_packed(text, offs, max_len=L)
+    ids = out["input_ids"]
+    got = tok.decode_batch(ids)
+    raw = text.tobytes()
+    exact = 0
+    for i in range(0, len(got), 7):
+        assert got[i] == O.decode(ids[i].tolist(), oracle_tables), i
+    unk = oracle_tables.unk_id
+    for i in range(len(got)):
+        n = int(out["n_real"][i])
+        if n < L and unk not in ids[i, :n]:
+            doc = raw[offs[i]:offs[i + 1]].decode("utf-8")
+            body = got[i].split(" </s>")[0][len("<s> "):] if n > 2 else ""
+            assert body.split() == doc.split(), i
+            exact += 1
+    assert exact > 10000

@@ -98,6 +98,24 @@ def test_g4_loader():
             _check_call(t, c)
 
 
+def test_g6_decode(oracle_tables):
+    """Tokenize.decode (tokenize.py:137-139) incl. the decoder snapshot rules (last word wins on an id collision)."""
+    from corpus import VOCAB_PATH, BPE_PATH
+    rows = read_jsonl("g6_decode.jsonl")
+    assert len(rows) == 5
+    for row in rows:
+        if "vocab_b64" in row:
+            t = O.Tables(base64.b64decode(row["vocab_b64"]), base64.b64decode(row["bpe_b64"]))
+            assert sorted(t.decoder.items()) == [tuple(x) for x in row["decoder"]], row["name"]
+        elif row["unk_token"] != "<unk>":
+            t = O.Tables(open(VOCAB_PATH, "rb").read(), open(BPE_PATH, "rb").read(),
+                         ("<pad>", "<s>", "</s>", "<mask>", row["unk_token"]))
+        else:
+            t = oracle_tables
+        for ids, want in zip(row["ids"], row["result"]):
+            assert O.decode(ids, t) == want, (row["name"], ids)
+
+
 def _block_hashes(t, text, offs, L, lo, hi):
     h_ids, h_mask, ntok = hashlib.sha256(), hashlib.sha256(), 0
     raw = text.tobytes()
