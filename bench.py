@@ -264,6 +264,19 @@ def main():
                        "text_bytes": int(need)}
         for q in (d_c, d_ro, d_oo, d_txt):
             ctx.free(q)
+        # secondary (8(f) rank 3): the five preprocess.py filters chained over the same resident text
+        d_po = ctx.alloc(in_bytes + 64); d_poo = ctx.alloc(8 * (n + 1))
+        pps = {}
+        for name, ops in (("all_five", [1, 2, 3, 4, 5]), ("remove_html", [1]), ("remove_emoji", [4])):
+            dts = []
+            for _ in range(3):
+                t_a = time.perf_counter()
+                kept = ctx.preprocess_device(ops, d_text, d_off, n, in_bytes, d_po, in_bytes, d_poo)
+                dts.append(time.perf_counter() - t_a)
+            pps[name] = {"ms": round(min(dts) * 1e3, 3), "MB_per_s": round(in_bytes / min(dts) / 1e6, 1), "bytes_out": int(kept)}
+        decode_info["preprocess"] = {"workload": "preprocess.py filters over the step's %d documents (%.1f MB), text resident in HBM, "
+                                                 "wall time incl. the per-filter size read-back" % (n, in_bytes / 1e6), **pps}
+        ctx.free(d_po); ctx.free(d_poo)
     tokens_local = int(n_real.sum())
     tot = np.array([in_bytes, tokens_local, n], dtype=np.float64)
     if dist is not None:
@@ -338,7 +351,7 @@ def main():
             "verified": verify,
             "merge_loop_only": merge_only,
             "configs_1_small_batch": small,
-            "decode_batch": decode_info,
+            "next_rows": decode_info,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(text, offs, L)

@@ -106,6 +106,7 @@ struct gz_ctx {
     std::string dec_unk;
     bool dec_unk_set = false;
     DBuf t_dec_entries, t_dec_bytes, w_dec_ids, w_dec_roff, w_dec_rb, w_dec_ooff, w_dec_out;
+    DBuf w_pp[2], w_ppoff[2], w_pplen, w_ppaux, w_pp_in, w_pp_inoff;      // text pre-pass
     bool building_words = false;         // the whole-word table is being built: ignore diagnostics
     bool no_words_env = false;           // GZ_WORD_TABLE=0 in the environment
 };
@@ -482,6 +483,7 @@ void gz_destroy(gz_ctx* c)
     if (c->ev_join) hipEventDestroy(c->ev_join);
     if (c->h_pick) hipHostFree(c->h_pick);
     release(c->w_pick); release(c->w_rowoff32);
+    for (DBuf* b : {&c->w_pp[0], &c->w_pp[1], &c->w_ppoff[0], &c->w_ppoff[1], &c->w_pplen, &c->w_ppaux, &c->w_pp_in, &c->w_pp_inoff}) release(*b);
     for (DBuf* b : {&c->t_dec_entries, &c->t_dec_bytes, &c->w_dec_ids, &c->w_dec_roff, &c->w_dec_rb, &c->w_dec_ooff, &c->w_dec_out}) release(*b);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
     for (DBuf* b : {&c->t_pair, &c->t_merges, &c->t_symids, &c->t_bmp, &c->t_astral, &c->t_struct, &c->t_words2, &c->t_words0, &c->w_text, &c->w_toff, &c->w_pair,
@@ -930,6 +932,91 @@ int gz_decode_batch(gz_ctx* c, const int32_t* ids, const int64_t* row_off, int64
     HIPCHK(c, hipMemcpyAsync(out, c->w_dec_out.p, (size_t)total, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
+    return GZ_OK;
+}
+
+// ---- text pre-pass ----------------------------------------------------------------------------------------------------
+namespace {
+// Runs the filters one after the other; the last one writes to out_dev / out_off_dev.  in_bytes = bytes of the input.
+int preprocess_device_locked(gz_ctx* c, const int32_t* ops, int32_t n_ops, const uint8_t* text_dev, const int64_t* off_dev,
+                             int64_t n_docs, int64_t in_bytes, uint8_t* out_dev, int64_t capacity, int64_t* out_off_dev, int64_t* total)
+{
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    for (int k = 0; k < n_ops; ++k) if (ops[k] < GZ_PP_HTML || ops[k] > GZ_PP_URL) return fail(c, GZ_E_INVALID, "unknown filter %d", ops[k]);
+    if ((rc = ensure(c, c->w_pplen, (size_t)(n_docs + 1) * 8))) return rc;
+    if ((rc = ensure(c, c->w_ppaux, (size_t)(n_docs + 1) * 8))) return rc;
+    const uint8_t* in = text_dev;
+    const int64_t* in_off = off_dev;
+    *total = in_bytes;
+    for (int k = 0; k < n_ops; ++k) {
+        const bool last = k == n_ops - 1;
+        DBuf& ob = c->w_pp[k & 1];
+        DBuf& oo = c->w_ppoff[k & 1];
+        if (!last) {
+            if ((rc = ensure(c, ob, (size_t)*total + 16))) return rc;      // a filter never grows a document
+            if ((rc = ensure(c, oo, (size_t)(n_docs + 1) * 8))) return rc;
+        }
+        GzPpArgs A{};
+        A.in = in; A.in_off = in_off; A.n_docs = n_docs; A.op = ops[k];
+        A.out_len = (int64_t*)c->w_pplen.p; A.aux = (int64_t*)c->w_ppaux.p;
+        A.out_off_w = last ? out_off_dev : (int64_t*)oo.p;
+        gz_launch_preprocess(A, 0, c->stream);
+        int64_t t = 0;
+        if (n_docs > 0) HIPCHK(c, hipMemcpyAsync(&t, A.out_off_w + n_docs, 8, hipMemcpyDeviceToHost, c->stream));
+        else HIPCHK(c, hipMemsetAsync(A.out_off_w, 0, 8, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        *total = t;
+        if (last && (!out_dev || t > capacity)) {
+            if (!out_dev) return GZ_OK;
+            return fail(c, GZ_E_CAPACITY, "pre-pass output needs %lld bytes, capacity is %lld", (long long)t, (long long)capacity);
+        }
+        A.out = last ? out_dev : (uint8_t*)ob.p;
+        A.out_off = A.out_off_w;
+        gz_launch_preprocess(A, 1, c->stream);
+        in = A.out; in_off = A.out_off;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    return GZ_OK;
+}
+}  // namespace
+
+int gz_preprocess_batch_device(gz_ctx* c, const int32_t* ops, int32_t n_ops, const uint8_t* text_dev, const int64_t* text_off_dev,
+                               int64_t n_docs, int64_t text_bytes, uint8_t* out_dev, int64_t capacity, int64_t* out_off_dev,
+                               int64_t* total_host)
+{
+    if (!c || !ops || n_ops < 1 || n_ops > 16 || !text_off_dev || !out_off_dev || !total_host || n_docs < 0 || text_bytes < 0 || capacity < 0)
+        return c ? fail(c, GZ_E_INVALID, "bad arguments") : GZ_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mu);
+    return preprocess_device_locked(c, ops, n_ops, text_dev, text_off_dev, n_docs, text_bytes, out_dev, capacity, out_off_dev, total_host);
+}
+
+int gz_preprocess_batch(gz_ctx* c, const int32_t* ops, int32_t n_ops, const uint8_t* text, const int64_t* text_off, int64_t n_docs,
+                        uint8_t* out, int64_t capacity, int64_t* out_off)
+{
+    if (!c || !ops || n_ops < 1 || n_ops > 16 || !text_off || !out_off || n_docs < 0 || capacity < 0 || (capacity > 0 && !out))
+        return c ? fail(c, GZ_E_INVALID, "bad arguments") : GZ_E_INVALID;
+    const int64_t nbytes = text_off[n_docs] - text_off[0];
+    if (nbytes < 0 || (nbytes > 0 && !text)) return fail(c, GZ_E_INVALID, "bad text offsets");
+    for (int64_t d = 0; d < n_docs; ++d) if (text_off[d + 1] < text_off[d]) return fail(c, GZ_E_INVALID, "text offsets must not decrease");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    int rc;
+    if ((rc = ensure(c, c->w_pp_in, (size_t)nbytes + 16))) return rc;
+    if ((rc = ensure(c, c->w_pp_inoff, (size_t)(n_docs + 1) * 8))) return rc;
+    DBuf& fin = c->w_dec_out;                                       // final text (shared scratch with decode)
+    DBuf& fino = c->w_dec_ooff;
+    if ((rc = ensure(c, fin, (size_t)nbytes + 16))) return rc;
+    if ((rc = ensure(c, fino, (size_t)(n_docs + 1) * 8))) return rc;
+    if (nbytes) HIPCHK(c, hipMemcpyAsync(c->w_pp_in.p, text + text_off[0], (size_t)nbytes, hipMemcpyHostToDevice, c->stream));
+    HIPCHK(c, hipMemcpyAsync(c->w_pp_inoff.p, text_off, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    int64_t total = 0;
+    if ((rc = preprocess_device_locked(c, ops, n_ops, (const uint8_t*)c->w_pp_in.p, (const int64_t*)c->w_pp_inoff.p, n_docs, nbytes,
+                                       (uint8_t*)fin.p, nbytes, (int64_t*)fino.p, &total))) return rc;
+    HIPCHK(c, hipMemcpy(out_off, fino.p, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost));
+    if (total > capacity) return fail(c, GZ_E_CAPACITY, "pre-pass output needs %lld bytes, capacity is %lld", (long long)total, (long long)capacity);
+    if (total) HIPCHK(c, hipMemcpy(out, fin.p, (size_t)total, hipMemcpyDeviceToHost));
     return GZ_OK;
 }
 

@@ -78,3 +78,15 @@ void gz_launch_bpe_word(const GzDeviceTables* T_dev, const uint8_t* word, int64_
 // batch decode: out == nullptr -> row_bytes[n_rows] + out_off[n_rows + 1] (exclusive scan); else write the text
 void gz_launch_decode(const GzDecTable& D, const int32_t* ids, const int64_t* row_off, int64_t n_rows, int64_t* row_bytes,
                       int64_t* out_off, uint8_t* out, int64_t capacity, hipStream_t s);
+
+// text pre-pass (gz_preproc.inc): one filter over packed documents
+struct GzPpArgs {
+    const uint8_t* in; const int64_t* in_off;   // document d = in[in_off[d] - in_off[0] .. in_off[d+1] - in_off[0])
+    int64_t n_docs;
+    uint8_t* out; const int64_t* out_off;       // pass 1: where document d goes
+    int64_t* out_len;                           // pass 0: bytes document d keeps ...
+    int64_t* out_off_w;                         // ... and their exclusive scan [n_docs + 1]
+    int64_t* aux;                               // [n_docs] filter state handed from pass 0 to pass 1 (html: unclosed '<')
+    int32_t op;                                 // GZ_PP_*
+};
+void gz_launch_preprocess(const GzPpArgs& A, int pass, hipStream_t s);

@@ -478,6 +478,7 @@ void gz_launch_pick(const int64_t* off, const int64_t* off2, int64_t n_docs, int
 
 #include "gz_pipeline.inc"
 #include "gz_decode.inc"
+#include "gz_preproc.inc"
 
 // =================================================================================================================
 // launchers
@@ -521,4 +522,20 @@ void gz_launch_decode(const GzDecTable& D, const int32_t* ids, const int64_t* ro
         hipLaunchKernelGGL(gz_decode_kernel, dim3(grid), dim3(WAVE * 4), 0, s, D, ids, row_off, n_rows, (int64_t*)nullptr,
                            (const int64_t*)out_off, out, capacity);
     }
+}
+
+// one filter, one pass (0: out_len + aux, then the caller scans; 1: write)
+void gz_launch_preprocess(const GzPpArgs& A, int pass, hipStream_t s)
+{
+    if (A.n_docs <= 0) return;
+    const dim3 grid((unsigned)((A.n_docs + 3) / 4)), block(WAVE * 4);
+    switch (A.op) {
+    case PP_HTML:    hipLaunchKernelGGL(gz_pp_kernel<PP_HTML>, grid, block, 0, s, A, pass); break;
+    case PP_UNICODE: hipLaunchKernelGGL(gz_pp_kernel<PP_UNICODE>, grid, block, 0, s, A, pass); break;
+    case PP_PUNCT:   hipLaunchKernelGGL(gz_pp_kernel<PP_PUNCT>, grid, block, 0, s, A, pass); break;
+    case PP_EMOJI:   hipLaunchKernelGGL(gz_pp_kernel<PP_EMOJI>, grid, block, 0, s, A, pass); break;
+    case PP_URL:     hipLaunchKernelGGL(gz_pp_kernel<PP_URL>, grid, block, 0, s, A, pass); break;
+    default: break;
+    }
+    if (pass == 0) hipLaunchKernelGGL(gz_scan_kernel, dim3(1), dim3(1024), 0, s, (const int64_t*)A.out_len, A.n_docs, A.out_off_w);
 }

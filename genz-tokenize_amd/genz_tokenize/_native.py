@@ -18,13 +18,15 @@ GZ_OK, GZ_E_INVALID, GZ_E_UTF8, GZ_E_HIP, GZ_E_NOTABLES = 0, -1, -2, -3, -4
 GZ_E_CAPACITY, GZ_E_LIMIT, GZ_E_NOMEM, GZ_E_RCCL, GZ_E_NODEVICE = -5, -6, -7, -8, -9
 GZ_PADDING, GZ_TRUNCATION, GZ_MAX_LEN_NONE, GZ_TIMING, GZ_NO_WORD_TABLE = 0x1, 0x2, 0x4, 0x100, 0x200
 GZ_NONE = -1
+GZ_PP_HTML, GZ_PP_UNICODE, GZ_PP_PUNCT, GZ_PP_EMOJI, GZ_PP_URL = 1, 2, 3, 4, 5
 
 # every symbol include/genz_tokenize.h declares (tests/test_abi.py checks the export list against the header)
 SYMBOLS = [
     "gz_version", "gz_create", "gz_destroy", "gz_last_error", "gz_load_tables", "gz_table_info",
     "gz_vocab_entry", "gz_merge_entry", "gz_encode_batch", "gz_encode_batch_device", "gz_sync",
     "gz_word_token_counts", "gz_bpe_word", "gz_symbol_utf8", "gz_device_alloc", "gz_device_free", "gz_memcpy_h2d", "gz_memcpy_d2h",
-    "gz_timing", "gz_decoder_snapshot", "gz_decode_batch", "gz_decode_batch_device", "gz_comm_unique_id", "gz_comm_init", "gz_gather_rows", "gz_compact_rows", "gz_expand_rows",
+    "gz_timing", "gz_decoder_snapshot", "gz_decode_batch", "gz_decode_batch_device", "gz_preprocess_batch",
+    "gz_preprocess_batch_device", "gz_comm_unique_id", "gz_comm_init", "gz_gather_rows", "gz_compact_rows", "gz_expand_rows",
     "gz_host_tables_create", "gz_host_tables_destroy", "gz_host_tables_array", "gz_host_tables_vocab_entry",
     "gz_host_tables_merge_entry", "gz_host_tables_symbol",
 ]
@@ -73,6 +75,8 @@ def load_library():
     L.gz_decoder_snapshot.argtypes = [vp]
     L.gz_decode_batch.argtypes = [vp, vp, vp, i64, vp, i32, vp, i64, vp]
     L.gz_decode_batch_device.argtypes = [vp, vp, vp, i64, vp, i32, vp, i64, vp, P(i64)]
+    L.gz_preprocess_batch.argtypes = [vp, vp, i32, vp, vp, i64, vp, i64, vp]
+    L.gz_preprocess_batch_device.argtypes = [vp, vp, i32, vp, vp, i64, i64, vp, i64, vp, P(i64)]
     L.gz_comm_unique_id.argtypes = [vp]
     L.gz_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
     L.gz_gather_rows.argtypes = [vp, vp, i64, i32, vp, vp, C.c_int]
@@ -310,6 +314,28 @@ class Context:
         self._check(self.lib.gz_decode_batch_device(self.handle, C.c_void_p(d_ids), C.c_void_p(d_row_off), n_rows,
                                                     C.cast(ub, C.c_void_p), len(unk), C.c_void_p(d_out) if d_out else None,
                                                     capacity, C.c_void_p(d_out_off), C.byref(total)))
+        return total.value
+
+    # ---- text pre-pass ----------------------------------------------------------------------------------
+    def preprocess(self, ops, text: np.ndarray, text_off: np.ndarray):
+        """packed UTF-8 + int64 offsets -> (packed UTF-8, int64 offsets) after applying the GZ_PP_* filters in order."""
+        ops = np.ascontiguousarray(ops, dtype=np.int32)
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        text_off = np.ascontiguousarray(text_off, dtype=np.int64)
+        n = len(text_off) - 1
+        cap = int(text_off[n] - text_off[0])
+        out = np.empty(max(cap, 1), dtype=np.uint8)
+        out_off = np.zeros(n + 1, dtype=np.int64)
+        self._check(self.lib.gz_preprocess_batch(self.handle, _ptr(ops), len(ops), _ptr(text) if len(text) else None,
+                                                 _ptr(text_off), n, _ptr(out), cap, _ptr(out_off)))
+        return out[:int(out_off[n])], out_off
+
+    def preprocess_device(self, ops, d_text, d_off, n_docs, text_bytes, d_out, capacity, d_out_off) -> int:
+        ops = np.ascontiguousarray(ops, dtype=np.int32)
+        total = C.c_int64()
+        self._check(self.lib.gz_preprocess_batch_device(self.handle, _ptr(ops), len(ops), C.c_void_p(d_text), C.c_void_p(d_off),
+                                                        n_docs, text_bytes, C.c_void_p(d_out) if d_out else None, capacity,
+                                                        C.c_void_p(d_out_off), C.byref(total)))
         return total.value
 
     def compact_rows(self, d_rows, d_n_real, n_rows, row_len, d_out) -> int:

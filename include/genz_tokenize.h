@@ -177,6 +177,29 @@ int  gz_decode_batch(gz_ctx *ctx, const int32_t *ids, const int64_t *row_off, in
 int  gz_decode_batch_device(gz_ctx *ctx, const int32_t *ids_dev, const int64_t *row_off_dev, int64_t n_rows, const uint8_t *unk,
                             int32_t unk_len, uint8_t *out_dev, int64_t capacity, int64_t *out_off_dev, int64_t *total_host);
 
+/* ---- text pre-pass: the string filters of genz_tokenize/preprocess.py on packed documents ----
+ *   GZ_PP_HTML     remove_html          preprocess.py:5-9     re.sub(r'<[^>]*>', '', txt)
+ *   GZ_PP_UNICODE  convert_unicode      preprocess.py:16-36   base letter + combining tone mark -> precomposed letter
+ *   GZ_PP_PUNCT    remove_punctuations  preprocess.py:39-44   drop string.punctuation
+ *   GZ_PP_EMOJI    remove_emoji         preprocess.py:47-72   drop the listed ranges, then ' '.join(s.split())
+ *   GZ_PP_URL      remove_URL           preprocess.py:75-80   re.sub(r'http\S+', '', txt)
+ * `ops[n_ops]` are applied in order to every document (vncore_tokenize, preprocess.py:83-89, talks to an external Java
+ * server and is not part of this library).  Input and output use the packed layout of gz_encode_batch (the output can
+ * be handed straight to it).  No filter grows a document, so capacity = input bytes always suffices; GZ_E_CAPACITY
+ * is returned otherwise and out_off is still valid.  No tables are needed.
+ * gz_preprocess_batch_device: the same with text / offsets / outputs resident in HBM; text_bytes = bytes of the input
+ * text; *total_host = bytes written (or needed); out_dev may be NULL to size the output only. */
+#define GZ_PP_HTML    1
+#define GZ_PP_UNICODE 2
+#define GZ_PP_PUNCT   3
+#define GZ_PP_EMOJI   4
+#define GZ_PP_URL     5
+int  gz_preprocess_batch(gz_ctx *ctx, const int32_t *ops, int32_t n_ops, const uint8_t *text, const int64_t *text_off,
+                         int64_t n_docs, uint8_t *out, int64_t capacity, int64_t *out_off);
+int  gz_preprocess_batch_device(gz_ctx *ctx, const int32_t *ops, int32_t n_ops, const uint8_t *text_dev, const int64_t *text_off_dev,
+                                int64_t n_docs, int64_t text_bytes, uint8_t *out_dev, int64_t capacity, int64_t *out_off_dev,
+                                int64_t *total_host);
+
 /* Multi-GPU exchange step (one process per GPU, RCCL over xGMI).  rank 0 creates an id, every rank calls
  * gz_comm_init with it; gz_gather_rows sends each rank's [n_rows, row_len] int32 device block to `root`,
  * which receives them back to back in rank order (grouped ncclSend/ncclRecv: each peer uses its own link). */

@@ -17,6 +17,9 @@ fixtures written here are data only (inputs + the reference's outputs):
   g6_decode.jsonl     Tokenize.decode on seeded random id lists (bundled tables, ids of '@@' pieces at the end of a
                       row, out-of-range / negative ids, a non-default unk_token) and on tiny tables whose words
                       contain spaces, '@@ ' and empty strings (file bytes stored base64)
+  g7_preprocess.jsonl.gz  the five text filters of genz_tokenize/preprocess.py (remove_html, convert_unicode,
+                      remove_punctuations, remove_emoji, remove_URL) on hand-picked and seeded random strings, one
+                      filter at a time and chained
   g5_hashes.json      SHA-256 of the reference's input_ids/attention_mask over the seeded
                       synthetic corpora of corpus.py (corpora are re-generated from seed)
 """
@@ -337,8 +340,69 @@ def g6(tok):
     jl("g6_decode.jsonl", rows)
 
 
+# ------------------------------------------------------------------ G7
+def g7():
+    from genz_tokenize import preprocess as P
+    fns = {"html": P.remove_html, "unicode": P.convert_unicode, "punct": P.remove_punctuations,
+           "emoji": P.remove_emoji, "url": P.remove_URL}
+    r = random.Random(707)
+    ws = [chr(c) for c in (0x09, 0x0A, 0x0B, 0x0C, 0x0D, 0x1C, 0x1D, 0x1E, 0x1F, 0x20, 0x85, 0xA0, 0x1680, 0x2000, 0x2003,
+                           0x200A, 0x2028, 0x2029, 0x202F, 0x205F, 0x3000)]
+    edge_cps = [0x24C1, 0x24C2, 0x2500, 0x2BEF, 0x2BF0, 0x2B55, 0x2B56, 0x2640, 0x2642, 0x2643, 0x2600, 0x25FF, 0x2702, 0x27B0,
+                0x200B, 0x200C, 0x200D, 0x200E, 0x23CF, 0x23E9, 0x231A, 0x231B, 0xFE0E, 0xFE0F, 0x3030, 0x3031, 0xFFFD, 0xFFFF,
+                0x10000, 0x1F251, 0x1F252, 0x1F600, 0x1F64F, 0x1F926, 0x1F937, 0x10FFFF, 0x4E2D, 0xAC00, 0xD7FF, 0xE000,
+                0xD800, 0xDFFF, 0x24B6, 0x1EA0, 0x0300, 0x0301, 0x0303, 0x0309, 0x0323, 0x0302, 0x031B]
+    import unicodedata
+    vi = ["sinh_vi\u00ean", "c\u00f4ng_ngh\u1ec7", "Vi\u1ec7t", "Nam", "\u0111\u1eb9p", "qu\u00e1", "ng\u01b0\u1eddi", "tr\u01b0\u1eddng", "h\u1ecdc",
+          "\u1ee8ng_d\u1ee5ng", "Y\u1ebfn", "\u00dd", "ngh\u0129a", "kh\u00f4ng", "\u0111\u01b0\u1ee3c"]
+    vi = [w.encode().decode("unicode_escape") if "\\u" in w else w for w in vi]
+    pieces_html = ["<b>", "</b>", "<a href=\"http://x.vn/a?b=1\">", "<br/>", "<", ">", "<<", ">>", "<>", "< >", "<p\nclass='x'>", "<!-- c -->",
+                   "a<b", "a>b", "<\u0111>"]
+    pieces_url = ["http", "https", "http:", "http://a.b/c", "https://vnexpress.net/tin-tuc?x=1&y=2", "xhttp://q", "httphttp", "htt", "ttp",
+                  "HTTP://x", "http\u00a0x", "http\u3000", "http\u200bx", "http\n", "(http://x)", "http\u0300"]
+
+    def rand_text():
+        k = r.choice([0, 1, 2, 3, 5, 8, 13, 21, 40, 90])
+        out = []
+        for _ in range(k):
+            m = r.random()
+            if m < 0.25:
+                w = r.choice(vi)
+                out.append(unicodedata.normalize("NFD", w) if r.random() < 0.5 else w)
+            elif m < 0.35: out.append(r.choice(pieces_html))
+            elif m < 0.45: out.append(r.choice(pieces_url))
+            elif m < 0.55: out.append(chr(r.choice(edge_cps)))
+            elif m < 0.62: out.append(r.choice("aâăeêioôơuưyAÂĂEÊIOÔƠUƯYbdx") + chr(r.choice([0x300, 0x301, 0x303, 0x309, 0x323, 0x302, 0x306])))
+            elif m < 0.70: out.append("".join(r.choice("!\"#$%&'()*+,-./:;<=>?@[\\]^_`{|}~") for _ in range(r.randint(1, 3))))
+            elif m < 0.76: out.append(chr(r.choice([0x1F600, 0x1F603, 0x1F44D, 0x2764, 0xFE0F, 0x1F1FB, 0x1F1F3, 0x263A, 0x2B50])))
+            else: out.append("".join(r.choice("abcdehptnx01 ") for _ in range(r.randint(1, 6))))
+            if r.random() < 0.6:
+                out.append(r.choice(ws) if r.random() < 0.35 else " ")
+        return "".join(out)
+
+    fixed = ["", " ", "<", ">", "<>", "a<b>c", "<a><b>", "<a<b>c>d", "x<y", "x>y<", "<<<>>>", "<a\n\n>b", "a <b c", "<b>bold</b> text <i",
+             "http", "http ", " http", "httpx", "http://", "see http://a.b now", "http://a http://b", "ahttphttpb c", "https", "xhttp",
+             "http\u00a0", "a\u0300", "A\u0323", "a\u0302\u0301", "\u00e2\u0301", "y\u0303Y\u0309", "\u0300a", "aa\u0300\u0300",
+             "o\u031b\u0301", "\u01a1\u0301", "!!!", "a.b,c", "\U0001F600", "a\U0001F600b", "a \U0001F600 b", "  a  b  ", "\u3000a\u3000b",
+             "a\u200db", "\u24c1\u24c2", "x\ufe0f", "\u4e2d\u6587 text", "a\tb\nc\r\nd", "\u2028x\u2029", "tab\x1cfs", "\ud800x", "end\udfff"]
+    texts = fixed + [rand_text() for _ in range(1200)]
+    rows = []
+    for t in texts:
+        for name, fn in fns.items():
+            rows.append({"ops": [name], "text": t, "result": fn(t)})
+    chains = [["html", "url", "emoji"], ["unicode", "punct"], ["url", "html"], ["emoji", "punct", "unicode"],
+              ["html", "unicode", "punct", "emoji", "url"], ["punct", "html"], ["emoji", "emoji"], ["url", "url"]]
+    for t in texts[::3]:
+        for ch in chains:
+            x = t
+            for name in ch:
+                x = fns[name](x)
+            rows.append({"ops": ch, "text": t, "result": x})
+    jl("g7_preprocess.jsonl.gz", rows)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6"]
+    which = sys.argv[1:] or ["g1", "g3", "g4", "g5", "g6", "g7"]
     tok = Tokenize()
     if "g1" in which: g1(tok)
     if "g3" in which: g3(tok)
@@ -346,3 +410,4 @@ if __name__ == "__main__":
     if "g5" in which: g5(False)
     if "g5full" in which: g5(True)
     if "g6" in which: g6(tok)
+    if "g7" in which: g7()

@@ -372,3 +372,47 @@ def test_encode_decode_round_trip(tok, oracle_tables, sampler):
             assert body.split() == doc.split(), i
             exact += 1
     assert exact > 10000
+
+
+def test_g7_preprocess(oracle_tables):
+    """The text pre-pass (remove_html / convert_unicode / remove_punctuations / remove_emoji / remove_URL) on the GPU
+    against the reference's outputs, one filter at a time and chained; batched by filter chain."""
+    from genz_tokenize import preprocess as P
+    rows = read_jsonl("g7_preprocess.jsonl.gz")
+    groups = {}
+    for r in rows:
+        groups.setdefault(tuple(r["ops"]), []).append(r)
+    assert len(groups) >= 13
+    for ops, rs in groups.items():
+        got = P.preprocess_batch([r["text"] for r in rs], list(ops))
+        for r, g in zip(rs, got):
+            assert g == r["result"], (ops, r["text"], g)
+    # the single-call drop-in names
+    for r in rows[:300]:
+        fn = {"html": P.remove_html, "unicode": P.convert_unicode, "punct": P.remove_punctuations, "emoji": P.remove_emoji,
+              "url": P.remove_URL}[r["ops"][0]]
+        assert fn(r["text"]) == r["result"]
+    assert P.preprocess_batch([], ["html"]) == []
+    with pytest.raises(TypeError):
+        P.remove_html(None)
+
+
+def test_preprocess_long_documents_vs_oracle():
+    """Documents far longer than a tile: tags, URLs and whitespace runs that straddle tile boundaries, open tags that
+    never close, and every filter's carried state."""
+    import random
+    from genz_tokenize import preprocess as P
+    r = random.Random(77)
+    parts = ["<b>", "</b>", "<a href='http://x.vn/", "'>", "<", ">", "http://vnexpress.net/" + "a" * 90, "https", "http", " ", "  ", "\n",
+             "\u3000", "\u00a0", "\u2003", "\U0001F600", "\u2764\ufe0f", "\u4e2d\u6587", "a\u0300", "\u00e2\u0301", "\u01b0\u0323", "Y\u0309",
+             "x\u0301", "\u0300", "vi\u1ec7t", "nam", "!?.,", "@#", "\u1ee9ng_d\u1ee5ng", "e" * 70, "<" + "q" * 130 + ">", "\t"]
+    docs = []
+    for n in [1, 5, 63, 64, 65, 127, 128, 129, 500, 2000, 9000]:
+        for _ in range(6):
+            docs.append("".join(r.choice(parts) for _ in range(n)))
+    docs += ["<" + "a" * 300, "a" * 64 + ">" + "<" * 64, "http" + "x" * 200 + " y", " " * 200 + "a" + " " * 200, "", "\U0001F600" * 100,
+             ("a\u0300" * 40), "x" * 63 + "a\u0300", "x" * 62 + "\u00e2\u0301", "x" * 63 + "\u00e2\u0301", "x" * 61 + "http://a b"]
+    for ops in (["html"], ["unicode"], ["punct"], ["emoji"], ["url"], ["html", "url", "unicode", "emoji", "punct"], ["url", "html"]):
+        got = P.preprocess_batch(docs, ops)
+        for d, g in zip(docs, got):
+            assert g == O.preprocess(d, ops), (ops, d[:80])

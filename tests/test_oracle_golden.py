@@ -116,6 +116,14 @@ def test_g6_decode(oracle_tables):
             assert O.decode(ids, t) == want, (row["name"], ids)
 
 
+def test_g7_preprocess():
+    """The five text filters of preprocess.py, one at a time and chained."""
+    rows = read_jsonl("g7_preprocess.jsonl.gz")
+    assert len(rows) > 9000
+    for row in rows:
+        assert O.preprocess(row["text"], row["ops"]) == row["result"], (row["ops"], row["text"])
+
+
 def _block_hashes(t, text, offs, L, lo, hi):
     h_ids, h_mask, ntok = hashlib.sha256(), hashlib.sha256(), 0
     raw = text.tobytes()
