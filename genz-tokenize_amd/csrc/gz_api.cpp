@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <atomic>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -1018,6 +1019,68 @@ int gz_preprocess_batch(gz_ctx* c, const int32_t* ops, int32_t n_ops, const uint
     if (total > capacity) return fail(c, GZ_E_CAPACITY, "pre-pass output needs %lld bytes, capacity is %lld", (long long)total, (long long)capacity);
     if (total) HIPCHK(c, hipMemcpy(out, fin.p, (size_t)total, hipMemcpyDeviceToHost));
     return GZ_OK;
+}
+
+// ---- DLPack hand-off ---------------------------------------------------------------------------------------------------
+// The deleter a consumer (torch, ...) calls may run while the Python interpreter shuts down, so it must be plain C:
+// a refcounted block owns the HBM allocation, every exported DLManagedTensor holds one reference.
+struct gz_block {
+    std::atomic<int> refs{1};
+    void* dptr = nullptr;
+    int device = 0;
+};
+namespace {
+struct DlDevice { int32_t device_type, device_id; };
+struct DlDataType { uint8_t code, bits; uint16_t lanes; };
+struct DlTensor { void* data; DlDevice device; int32_t ndim; DlDataType dtype; int64_t* shape; int64_t* strides; uint64_t byte_offset; };
+struct DlManagedTensor { DlTensor dl_tensor; void* manager_ctx; void (*deleter)(DlManagedTensor*); };   // dlpack.h, legacy ABI
+
+void block_release(gz_block* b)
+{
+    if (b && b->refs.fetch_sub(1) == 1) {
+        if (b->dptr) hipFree(b->dptr);
+        delete b;
+    }
+}
+void dl_deleter(DlManagedTensor* mt)
+{
+    if (!mt) return;
+    block_release((gz_block*)mt->manager_ctx);
+    free(mt->dl_tensor.shape);
+    free(mt);
+}
+}  // namespace
+
+int gz_block_create(gz_ctx* c, void* dptr, gz_block** out)
+{
+    if (!c || !dptr || !out) return c ? fail(c, GZ_E_INVALID, "bad arguments") : GZ_E_INVALID;
+    gz_block* b = new (std::nothrow) gz_block();
+    if (!b) return fail(c, GZ_E_NOMEM, "out of memory");
+    b->dptr = dptr; b->device = c->device;
+    *out = b;
+    return GZ_OK;
+}
+
+void gz_block_release(gz_block* b) { block_release(b); }
+
+void* gz_block_dlpack(gz_block* b, int32_t ndim, const int64_t* shape, int32_t dtype_code, int32_t dtype_bits)
+{
+    if (!b || ndim < 0 || ndim > 8 || (ndim && !shape)) return nullptr;
+    DlManagedTensor* mt = (DlManagedTensor*)calloc(1, sizeof(DlManagedTensor));
+    int64_t* sh = (int64_t*)malloc(sizeof(int64_t) * (size_t)(ndim ? ndim : 1));
+    if (!mt || !sh) { free(mt); free(sh); return nullptr; }
+    for (int i = 0; i < ndim; ++i) sh[i] = shape[i];
+    mt->dl_tensor.data = b->dptr;
+    mt->dl_tensor.device = DlDevice{10 /* kDLROCM */, b->device};
+    mt->dl_tensor.ndim = ndim;
+    mt->dl_tensor.dtype = DlDataType{(uint8_t)dtype_code, (uint8_t)dtype_bits, 1};
+    mt->dl_tensor.shape = sh;
+    mt->dl_tensor.strides = nullptr;
+    mt->dl_tensor.byte_offset = 0;
+    b->refs.fetch_add(1);
+    mt->manager_ctx = b;
+    mt->deleter = dl_deleter;
+    return mt;
 }
 
 // ---- compact rows for the exchange step -----------------------------------------------------------------------------

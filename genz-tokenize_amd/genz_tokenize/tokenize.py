@@ -67,17 +67,23 @@ class Tokenize(object):
         self._bpe_text = ""
         self._dicts = {}
         self._dirty = True
+        self._snapshot_pending = False
         self.add_vocab_file(self.vocab_file)
-        self._decoder_snapshot = None           # tokenize.py:40: decoder is built once, after the first vocab load
-        self._sync_tables()
-        self._decoder_snapshot = {v: k for k, v in self.encoder.items()}
-        self._ctx.decoder_snapshot()            # the same snapshot on the device (decode_batch)
+        # tokenize.py:40: `decoder` is built ONCE, here, from the first vocab load; a later add_vocab_file does not
+        # change it.  Both snapshots are taken lazily: the host dict when `.decoder` / decode() is first used, the
+        # device one with the first table build (the merges loaded next do not touch `encoder`).
+        self._decoder_snapshot = None
+        self._snapshot_source = (self._vocab_texts[0], (pad_token, bos_token, eos_token, mask_token, unk_token))
+        self._snapshot_pending = True
         self.add_bpe_file(self.bpe_file)
 
     # ---- tables -------------------------------------------------------------------------------------------
     def add_vocab_file(self, vocab_file):
         """tokenize.py:44-51 -- appends words to `encoder`; the device tables are rebuilt lazily."""
-        self._vocab_texts.append(_read_text(vocab_file))
+        text = _read_text(vocab_file)
+        if getattr(self, "_snapshot_pending", False):
+            self._sync_tables()                 # take the device decoder snapshot before the vocabulary grows
+        self._vocab_texts.append(text)
         self._dirty = True
 
     def add_bpe_file(self, bpe_file):
@@ -97,6 +103,9 @@ class Tokenize(object):
                               (self.pad_token, self.bos_token, self.eos_token, self.mask_token, self.unk_token))
         self._dicts = {}
         self._dirty = False
+        if self._snapshot_pending:
+            self._ctx.decoder_snapshot()
+            self._snapshot_pending = False
 
     @property
     def encoder(self) -> Dict[str, int]:
@@ -107,6 +116,12 @@ class Tokenize(object):
 
     @property
     def decoder(self) -> Dict[int, str]:
+        if self._decoder_snapshot is None:
+            text, specials = self._snapshot_source
+            vocab = (text if (text == "" or text.endswith("\n")) else text + "\n").encode("utf-8")
+            ht = _native.HostTables(vocab, b"", specials)
+            self._decoder_snapshot = {v: k for k, v in ht.vocab_items()}
+            ht.close()
         return self._decoder_snapshot
 
     @property
@@ -192,6 +207,7 @@ class Tokenize(object):
             if rows:
                 np.cumsum([len(r) for r in rows], out=off[1:])
             flat = np.concatenate(rows) if rows else np.zeros(0, dtype=np.int64)
+        self._sync_tables()
         flat = np.asarray(flat)
         if flat.dtype != np.int32:
             if flat.dtype.kind not in "iu":
@@ -286,6 +302,55 @@ class Tokenize(object):
         r = self._ctx.encode(text_u8, offsets, pair_u8, pair_offsets, max_len, bool(padding), bool(truncation),
                              0 if word_table else _native.GZ_NO_WORD_TABLE)
         return self._shape(r, len(offsets) - 1)
+
+    def encode_to_device(self, texts: Sequence[str], pair_texts: Optional[Sequence[str]] = None, max_len: int = 128):
+        """Batch `__call__` (padding=True, truncation=True) whose [N, max_len] int32 outputs STAY in HBM: a dict with the field names
+        of the reference's DataCollection (models/bert/dataset.py:7-28) -- input_ids, attention_mask and, with pair
+        texts, token_type_ids / sequence_id -- as `handoff.DeviceArray`s (DLPack: `torch.from_dlpack(x)` is zero-copy),
+        plus host arrays n_real [N] and status [N]."""
+        from .handoff import DeviceArray
+        if max_len is None or int(max_len) < 1:
+            raise ValueError("encode_to_device needs max_len >= 1 (dense rows)")
+        self._sync_tables()
+        ctx, L = self._ctx, int(max_len)
+        t, to = _pack(texts)
+        n = len(to) - 1
+        pair = pair_texts is not None
+        if pair:
+            if len(pair_texts) != n:
+                raise ValueError("texts and pair_texts differ in length")
+            p, po = _pack(pair_texts)
+        bufs = []
+
+        def up(a):
+            d = ctx.alloc(max(a.nbytes, 1) + 64)
+            bufs.append(d)
+            if a.nbytes:
+                ctx.h2d(d, np.ascontiguousarray(a))
+            return d
+        try:
+            d_t, d_to = up(t), up(to)
+            d_p, d_po = (up(p), up(po)) if pair else (0, 0)
+            cells = max(n * L, 1)
+            out = {k: DeviceArray(ctx, ctx.alloc(4 * cells), (n, L)) for k in
+                   (("input_ids", "attention_mask", "token_type_ids", "sequence_id") if pair else ("input_ids", "attention_mask"))}
+            d_nr, d_st, d_pl = ctx.alloc(4 * max(n, 1)), ctx.alloc(4 * max(n, 1)), ctx.alloc(8 * max(n, 1))
+            bufs += [d_nr, d_st, d_pl]
+            flags = _native.GZ_PADDING | _native.GZ_TRUNCATION
+            ctx.encode_device(d_t, d_to, d_p, d_po, n, L, flags, n * L, out["input_ids"].ptr, out["attention_mask"].ptr,
+                              out["token_type_ids"].ptr if pair else None, out["sequence_id"].ptr if pair else None,
+                              None, d_pl if pair else None, d_nr, d_st if pair else None)
+            ctx.sync()
+            nr = np.zeros(n, dtype=np.int32); st = np.zeros(n, dtype=np.int32)
+            if n:
+                ctx.d2h(nr, d_nr)
+                if pair:
+                    ctx.d2h(st, d_st)
+            out["n_real"], out["status"] = nr, st
+            return out
+        finally:
+            for d in bufs:
+                ctx.free(d)
 
     @staticmethod
     def _shape(r, n):

@@ -200,6 +200,17 @@ int  gz_preprocess_batch_device(gz_ctx *ctx, const int32_t *ops, int32_t n_ops, 
                                 int64_t n_docs, int64_t text_bytes, uint8_t *out_dev, int64_t capacity, int64_t *out_off_dev,
                                 int64_t *total_host);
 
+/* ---- model-feed hand-off --------------------------------------------------------------------
+ * Zero-copy export of an output buffer to a framework through DLPack.  gz_block_create takes ownership of a pointer
+ * obtained from gz_device_alloc (refcount 1); gz_block_dlpack returns a malloc'ed DLManagedTensor (dlpack.h layout,
+ * device type kDLROCM) that holds one more reference and whose deleter is a C function of this library, safe to call
+ * at interpreter shutdown; the HBM allocation is freed when the last reference goes.  The fields a consumer sees
+ * are the reference's DataCollection names (models/bert/dataset.py:7-28): input_ids, attention_mask, token_type_ids. */
+typedef struct gz_block gz_block;
+int   gz_block_create(gz_ctx *ctx, void *dptr, gz_block **out);
+void  gz_block_release(gz_block *block);
+void *gz_block_dlpack(gz_block *block, int32_t ndim, const int64_t *shape, int32_t dtype_code, int32_t dtype_bits);
+
 /* Multi-GPU exchange step (one process per GPU, RCCL over xGMI).  rank 0 creates an id, every rank calls
  * gz_comm_init with it; gz_gather_rows sends each rank's [n_rows, row_len] int32 device block to `root`,
  * which receives them back to back in rank order (grouped ncclSend/ncclRecv: each peer uses its own link). */

@@ -416,3 +416,14 @@ def test_preprocess_long_documents_vs_oracle():
         got = P.preprocess_batch(docs, ops)
         for d, g in zip(docs, got):
             assert g == O.preprocess(d, ops), (ops, d[:80])
+
+
+def test_device_handoff_dlpack():
+    """encode_to_device keeps the [N, L] outputs in HBM; torch.from_dlpack reads them zero-copy.  Runs in a child
+    process because torch must initialise its GPU context BEFORE this library is loaded (both resolve the HIP runtime
+    by soname; the first one loaded serves both) -- see tests/handoff_child.py."""
+    import subprocess, sys
+    pytest.importorskip("torch")
+    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "handoff_child.py")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "HANDOFF OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
