@@ -38,15 +38,18 @@ __device__ __forceinline__ int below(uint64_t m)
     return (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
 }
 
+// exclusive prefix sum over the wave, all in DPP (no LDS traffic): Hillis-Steele inside each row of 16 lanes
+// (row_shr 1, 2, 4, 8), then row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3.
 __device__ __forceinline__ int wave_excl_sum(int v, int lane, int& total)
 {
     int x = v;
-#pragma unroll
-    for (int d = 1; d < WAVE; d <<= 1) {
-        int y = __shfl_up(x, d, WAVE);
-        if (lane >= d) x += y;
-    }
-    total = __shfl(x, WAVE - 1, WAVE);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xF, 0xF, false);     // row_shr:1
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xF, 0xF, false);     // row_shr:2
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xF, 0xF, false);     // row_shr:4
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xF, 0xF, false);     // row_shr:8
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xA, 0xF, false);     // row_bcast:15 -> rows 1, 3
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xC, 0xF, false);     // row_bcast:31 -> rows 2, 3
+    total = __builtin_amdgcn_readlane(x, WAVE - 1);
     return x - v;
 }
 
