@@ -106,6 +106,8 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="(diagnostic) skip the RCCL gather at N > 1")
     ap.add_argument("--force-exchange", action="store_true",
                     help="(diagnostic) run the multi-GPU exchange step even with one rank (launch through torch.distributed.run)")
+    ap.add_argument("--expand-at-root", action="store_true",
+                    help="rank 0 also rebuilds dense [N, L] ids+mask of ALL ranks in every step (root-bound: 2 GB per rank)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-merge-only", action="store_true", help="skip the secondary run without the whole-word table")
@@ -147,61 +149,86 @@ def main():
     d_all_ids = d_all_mask = d_all_nreal = d_comp = 0
     all_comp = {"ptr": 0, "cap": 0}
     rows_per_rank = [n] * world
+    # Double-buffered outputs: step k is tokenized into set k & 1 while the exchange of step k-1 (other set) is in flight
+    # on the library's exchange stream.
+    nset = 2 if gather else 1
+    sets = [{"ids": d_ids, "mask": d_mask, "nreal": d_nreal}]
     if gather:
+        sets.append({"ids": ctx.alloc(4 * n * L), "mask": ctx.alloc(4 * n * L), "nreal": ctx.alloc(4 * n)})
         uid = [ctx.comm_unique_id() if rank == 0 else None]
         dist.broadcast_object_list(uid, src=0)
         ctx.comm_init(uid[0], rank, world)
-        d_comp = ctx.alloc(4 * n * L)                      # the rank's rows without their padding (worst case: all of it)
+        for st in sets:
+            st["comp"] = ctx.alloc(4 * n * L)              # the rank's rows without their padding (worst case: all of it)
         if rank == 0:
-            d_all_ids = ctx.alloc(4 * n * L * world); d_all_mask = ctx.alloc(4 * n * L * world)
             d_all_nreal = ctx.alloc(4 * n * world)
 
     kernel_ms = []
+    last_totals = [None]
 
-    def exchange():
-        """The exchange step: every rank sends its rows WITHOUT the padding (row lengths + leading entries) straight to
-        rank 0 over its own xGMI link (grouped ncclSend/ncclRecv); rank 0 re-creates padding and attention mask."""
-        total = ctx.compact_rows(d_ids, d_nreal, n, L, d_comp)
+    def exchange(st):
+        """The exchange step of one tokenized batch: every rank sends its rows WITHOUT the padding (row lengths + the
+        rows' real entries, CSR form) straight to rank 0 over its own xGMI link (grouped ncclSend/ncclRecv).  Rank 0
+        ends up with the ids of all documents; dense [N, L] ids / mask blocks are rebuilt from that on demand
+        (gz_expand_rows, done once after the timed region for the check below; --expand-at-root puts it in every step)."""
+        total = ctx.compact_rows(st["ids"], st["nreal"], n, L, st["comp"])
         t = torch.tensor([total], dtype=torch.int64, device="cuda")
         lst = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(lst, t)
         totals = [int(x.item()) for x in lst]
         if rank == 0 and sum(totals) > all_comp["cap"]:
+            ctx.sync()
             if all_comp["ptr"]:
                 ctx.free(all_comp["ptr"])
             all_comp["cap"] = int(sum(totals) * 1.05) + 1024
             all_comp["ptr"] = ctx.alloc(4 * all_comp["cap"])
-        ctx.gather_rows(d_nreal, n, 1, d_all_nreal, rows_per_rank, 0)
-        ctx.gather_rows(d_comp, total, 1, all_comp["ptr"], totals, 0)
-        if rank == 0:
-            ctx.expand_rows(all_comp["ptr"], d_all_nreal, n * world, L, d_all_ids, d_all_mask)
-        ctx.sync()
+        ctx.gather_rows(st["nreal"], n, 1, d_all_nreal if rank == 0 else 0, rows_per_rank, 0)
+        ctx.gather_rows(st["comp"], total, 1, all_comp["ptr"], totals, 0)
+        if rank == 0 and args.expand_at_root:
+            ctx.expand_rows(all_comp["ptr"], d_all_nreal, n * world, L, root_dense["ids"], root_dense["mask"])
+        last_totals[0] = totals
 
-    def step(record):
-        ctx.encode_device(d_text, d_off, 0, 0, n, L, flags, n * L, d_ids, d_mask, d_n_real=d_nreal)
+    root_dense = {}
+    if gather and rank == 0 and args.expand_at_root:
+        root_dense = {"ids": ctx.alloc(4 * n * L * world), "mask": ctx.alloc(4 * n * L * world)}
+
+    def run_steps(k_steps, record):
+        """k_steps tokenization steps; with an exchange, step k's kernels overlap the exchange of step k-1."""
+        for k in range(k_steps):
+            st = sets[k % nset]
+            ctx.encode_device(d_text, d_off, 0, 0, n, L, flags, n * L, st["ids"], st["mask"], d_n_real=st["nreal"])
+            if gather:
+                if k > 0:
+                    ctx.exchange_select(1)
+                    exchange(sets[(k - 1) % nset])
+            else:
+                ctx.sync()
+                if record:
+                    kernel_ms.append(ctx.timing()[0])
+        if gather and k_steps > 0:
+            ctx.exchange_select(0)
+            exchange(sets[(k_steps - 1) % nset])
         ctx.sync()
-        if record:
-            kernel_ms.append(ctx.timing()[0])
-        if gather:
-            exchange()
+        if gather and record and k_steps > 0:
+            kernel_ms.append(ctx.timing()[0])              # hipEvents of the last step's launches
 
     def fence():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step(False)
+    run_steps(args.warmup, False)
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step(True)
+    run_steps(args.steps, True)
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    last = sets[(args.steps - 1) % nset] if args.steps > 0 else sets[0]
+    d_ids, d_mask, d_nreal = last["ids"], last["mask"], last["nreal"]
 
     # ---- secondary measurement (untimed for `value`): the same step with the whole-word table switched off, i.e.
     # every word through the merge loop (DESIGN.md section 5)
@@ -308,11 +335,19 @@ def main():
                     sys.exit("bench: document %d differs from the oracle" % i)
             verify = "oracle on a 200-document stride sample: match"
         if gather:
-            blk = np.empty((n, L), dtype=np.int32); ctx.d2h(blk, d_all_ids)
-            mblk = np.empty((n, L), dtype=np.int32); ctx.d2h(mblk, d_all_mask)
-            if not (np.array_equal(blk, ids) and np.array_equal(mblk, mask)):
-                sys.exit("bench: gathered block of rank 0 differs from its local rows")
-            verify += "; gathered [%d, %d] ids+mask: rank 0's block equals its local rows" % (n * world, L)
+            # the gathered CSR block of the last step: row counts of every rank, and rank 0's own rows rebuilt from it
+            nr_all = np.empty(n * world, dtype=np.int32); ctx.d2h(nr_all, d_all_nreal)
+            tot = last_totals[0]
+            ok = all(int(nr_all[q * n:(q + 1) * n].sum()) == tot[q] for q in range(world))
+            d_ci, d_cm = ctx.alloc(4 * n * L), ctx.alloc(4 * n * L)
+            ctx.expand_rows(all_comp["ptr"], d_all_nreal, n, L, d_ci, d_cm)
+            ctx.sync()
+            blk = np.empty((n, L), dtype=np.int32); ctx.d2h(blk, d_ci)
+            mblk = np.empty((n, L), dtype=np.int32); ctx.d2h(mblk, d_cm)
+            if not (ok and np.array_equal(blk, ids) and np.array_equal(mblk, mask)):
+                sys.exit("bench: gathered block differs from the local rows / row counts")
+            verify += "; gathered CSR block (%d rows, %d ids): row counts of every rank add up, rank 0's rows expand to its local [n, %d] ids+mask" % (
+                n * world, sum(tot), L)
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -334,7 +369,7 @@ def main():
                                    "5%% 121-400 words), max_len=%d pad+trunc, bundled vocab" % (n, L),
                        "docs_total": total_docs, "input_bytes_total": int(total_bytes),
                        "tokens_total": int(total_tokens),
-                       "sharding": "dp%d by documents; exchange = RCCL gatherv (grouped send/recv) of row lengths + unpadded ids to rank 0, which rebuilds padding and mask%s" % (
+                       "sharding": "dp%d by documents; exchange = RCCL gatherv (grouped send/recv over direct xGMI links) of row lengths + unpadded ids (CSR) to rank 0, double-buffered under the next step's kernels%s" % (
                            world, "" if gather or world == 1 else " DISABLED (--no-gather)") if world > 1 else "single GPU",
                        "inputs": "resident in HBM before the timed region"},
             "roofline": {"bound": "hbm",

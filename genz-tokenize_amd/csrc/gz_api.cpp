@@ -97,6 +97,13 @@ struct gz_ctx {
     struct TextWs { DBuf brk, st, en, blkcnt, docw0, wtok, waux, mtok, mlist, blkmiss, blklong; } tw[2][2];   // [slot][text]
     hipStream_t stream2 = nullptr;       // sub-batches alternate between the two streams
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    // exchange step (compact / gather / expand) on its own stream, so that it overlaps the next call's kernels
+    hipStream_t xstream = nullptr;
+    hipEvent_t ev_tok[4] = {nullptr, nullptr, nullptr, nullptr};   // end of the last four encode calls
+    hipEvent_t ev_x = nullptr;                                       // last exchange operation issued
+    uint64_t enc_seq = 0;
+    int x_back = 0;                                                  // exchange ops depend on encode call (last - x_back)
+    bool x_used = false;
     DBuf w_pick, w_rowoff32;
     int64_t* h_pick = nullptr;           // pinned
     int64_t n_words = 0;
@@ -173,6 +180,7 @@ int enqueue(gz_ctx* c)
     gz_ctx::Pending& p = c->pend;
     hipStream_t s = c->stream;
     const GzDeviceTables* T = (const GzDeviceTables*)c->t_struct.p;
+    if (c->x_used) HIPCHK(c, hipStreamWaitEvent(s, c->ev_x, 0));    // output buffers may still be read by an exchange step
     HIPCHK(c, hipMemsetAsync(c->w_flags.p, 0, 16, s));     // [1] capacity error, [3] a word needs the wide / long kernels
     if (p.timing) HIPCHK(c, hipEventRecord(c->ev[0], s));
     const bool two = p.subs.size() > 1;
@@ -194,13 +202,30 @@ int enqueue(gz_ctx* c)
     if (p.pair) gz_launch_pair(c->dev, p.P, s);
     if (p.timing) HIPCHK(c, hipEventRecord(c->ev[3], s));
     HIPCHK(c, hipMemcpyAsync(c->h_flags, c->w_flags.p, 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipEventRecord(c->ev_tok[c->enc_seq & 3], s));
+    c->enc_seq++;
     HIPCHK(c, hipGetLastError());
+    return GZ_OK;
+}
+
+// exchange operations run on c->xstream, after the encode call they belong to (gz_exchange_select) and before any later
+// encode call touches the buffers again (enqueue waits for ev_x)
+int x_begin(gz_ctx* c)
+{
+    if (c->enc_seq > (uint64_t)c->x_back) HIPCHK(c, hipStreamWaitEvent(c->xstream, c->ev_tok[(c->enc_seq - 1 - (uint64_t)c->x_back) & 3], 0));
+    return GZ_OK;
+}
+int x_end(gz_ctx* c)
+{
+    HIPCHK(c, hipEventRecord(c->ev_x, c->xstream));
+    c->x_used = true;
     return GZ_OK;
 }
 
 int sync_locked(gz_ctx* c)
 {
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->x_used) HIPCHK(c, hipStreamSynchronize(c->xstream));
     gz_ctx::Pending& p = c->pend;
     if (!p.active) return GZ_OK;
     if (p.timing) {
@@ -468,6 +493,9 @@ int gz_create(int device_id, gz_ctx** out)
     hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
     hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+    hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking);
+    for (auto& e : c->ev_tok) hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    hipEventCreateWithFlags(&c->ev_x, hipEventDisableTiming);
     hipHostMalloc((void**)&c->h_pick, 256, hipHostMallocDefault);
     if (ensure(c, c->w_flags, 64) != GZ_OK) { g_create_err = c->err; gz_destroy(c); return GZ_E_NOMEM; }
     *out = c;
@@ -482,6 +510,9 @@ void gz_destroy(gz_ctx* c)
     if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); }
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
+    for (auto& e : c->ev_tok) if (e) hipEventDestroy(e);
+    if (c->ev_x) hipEventDestroy(c->ev_x);
+    if (c->xstream) hipStreamDestroy(c->xstream);
     if (c->h_pick) hipHostFree(c->h_pick);
     release(c->w_pick); release(c->w_rowoff32);
     for (DBuf* b : {&c->w_pp[0], &c->w_pp[1], &c->w_ppoff[0], &c->w_ppoff[1], &c->w_pplen, &c->w_ppaux, &c->w_pp_in, &c->w_pp_inoff}) release(*b);
@@ -1094,11 +1125,13 @@ int gz_compact_rows(gz_ctx* c, const int32_t* rows_dev, const int32_t* n_real_de
     int rc;
     if ((rc = ensure(c, c->w_rowoff32, (size_t)(n_rows + 2) * 4))) return rc;
     uint32_t* off = (uint32_t*)c->w_rowoff32.p;
-    gz_launch_row_offsets(n_real_dev, n_rows, off, c->stream);
-    gz_launch_compact(rows_dev, off, n_rows, row_len, out_dev, c->stream);
+    if ((rc = x_begin(c))) return rc;
+    gz_launch_row_offsets(n_real_dev, n_rows, off, c->xstream);
+    gz_launch_compact(rows_dev, off, n_rows, row_len, out_dev, c->xstream);
     uint32_t total = 0;
-    HIPCHK(c, hipMemcpyAsync(&total, off + n_rows, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipMemcpyAsync(&total, off + n_rows, 4, hipMemcpyDeviceToHost, c->xstream));
+    if ((rc = x_end(c))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->xstream));
     HIPCHK(c, hipGetLastError());
     *total_host = total;
     return GZ_OK;
@@ -1115,8 +1148,10 @@ int gz_expand_rows(gz_ctx* c, const int32_t* compact_dev, const int32_t* n_real_
     int rc;
     if ((rc = ensure(c, c->w_rowoff32, (size_t)(n_rows + 2) * 4))) return rc;
     uint32_t* off = (uint32_t*)c->w_rowoff32.p;
-    gz_launch_row_offsets(n_real_dev, n_rows, off, c->stream);
-    gz_launch_expand(compact_dev, off, n_rows, row_len, c->dev.pad_id, ids_dev, mask_dev, c->stream);
+    if ((rc = x_begin(c))) return rc;
+    gz_launch_row_offsets(n_real_dev, n_rows, off, c->xstream);
+    gz_launch_expand(compact_dev, off, n_rows, row_len, c->dev.pad_id, ids_dev, mask_dev, c->xstream);
+    if ((rc = x_end(c))) return rc;
     HIPCHK(c, hipGetLastError());
     return GZ_OK;
 }
@@ -1214,6 +1249,14 @@ int gz_comm_init(gz_ctx* c, const uint8_t id[128], int rank, int world)
     return GZ_OK;
 }
 
+int gz_exchange_select(gz_ctx* c, int back)
+{
+    if (!c || back < 0 || back > 2) return c ? fail(c, GZ_E_INVALID, "back must be 0, 1 or 2") : GZ_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->x_back = back;
+    return GZ_OK;
+}
+
 int gz_gather_rows(gz_ctx* c, const int32_t* send_dev, int64_t n_rows_local, int32_t row_len, int32_t* recv_dev,
                    const int64_t* rows_per_rank, int root)
 {
@@ -1224,6 +1267,7 @@ int gz_gather_rows(gz_ctx* c, const int32_t* send_dev, int64_t n_rows_local, int
         return fail(c, GZ_E_INVALID, "bad arguments");
     HIPCHK(c, hipSetDevice(c->device));
     const int ncclInt32 = 2;
+    { int rc0 = x_begin(c); if (rc0) return rc0; }
     // direct gatherv: the root posts one receive per peer, each peer one send, all inside one group, so every
     // peer's block travels over its own xGMI link concurrently (no ring)
     int r = g_rccl.GroupStart();
@@ -1234,19 +1278,20 @@ int gz_gather_rows(gz_ctx* c, const int32_t* send_dev, int64_t n_rows_local, int
             int32_t* dst = recv_dev + row0 * (int64_t)row_len;
             if (q == root) {
                 if (cnt && dst != send_dev)
-                    HIPCHK(c, hipMemcpyAsync(dst, send_dev, cnt * 4, hipMemcpyDeviceToDevice, c->stream));
+                    HIPCHK(c, hipMemcpyAsync(dst, send_dev, cnt * 4, hipMemcpyDeviceToDevice, c->xstream));
             } else if (cnt) {
-                r = g_rccl.Recv(dst, cnt, ncclInt32, q, c->comm, c->stream);
+                r = g_rccl.Recv(dst, cnt, ncclInt32, q, c->comm, c->xstream);
             }
             row0 += rows_per_rank[q];
         }
     } else if (r == 0) {
         const size_t cnt = (size_t)n_rows_local * (size_t)row_len;
-        if (cnt) r = g_rccl.Send(send_dev, cnt, ncclInt32, root, c->comm, c->stream);
+        if (cnt) r = g_rccl.Send(send_dev, cnt, ncclInt32, root, c->comm, c->xstream);
     }
     int r2 = g_rccl.GroupEnd();
     if (r != 0 || r2 != 0)
         return fail(c, GZ_E_RCCL, "RCCL gather failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r ? r : r2) : "error");
+    { int rc1 = x_end(c); if (rc1) return rc1; }
     return GZ_OK;
 }
 

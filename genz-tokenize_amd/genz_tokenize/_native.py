@@ -26,7 +26,7 @@ SYMBOLS = [
     "gz_vocab_entry", "gz_merge_entry", "gz_encode_batch", "gz_encode_batch_device", "gz_sync",
     "gz_word_token_counts", "gz_bpe_word", "gz_symbol_utf8", "gz_device_alloc", "gz_device_free", "gz_memcpy_h2d", "gz_memcpy_d2h",
     "gz_timing", "gz_decoder_snapshot", "gz_decode_batch", "gz_decode_batch_device", "gz_preprocess_batch",
-    "gz_preprocess_batch_device", "gz_block_create", "gz_block_release", "gz_block_dlpack", "gz_comm_unique_id", "gz_comm_init", "gz_gather_rows", "gz_compact_rows", "gz_expand_rows",
+    "gz_preprocess_batch_device", "gz_block_create", "gz_block_release", "gz_block_dlpack", "gz_exchange_select", "gz_comm_unique_id", "gz_comm_init", "gz_gather_rows", "gz_compact_rows", "gz_expand_rows",
     "gz_host_tables_create", "gz_host_tables_destroy", "gz_host_tables_array", "gz_host_tables_vocab_entry",
     "gz_host_tables_merge_entry", "gz_host_tables_symbol",
 ]
@@ -80,6 +80,7 @@ def load_library():
     L.gz_block_create.argtypes = [vp, vp, P(vp)]
     L.gz_block_release.argtypes = [vp]; L.gz_block_release.restype = None
     L.gz_block_dlpack.argtypes = [vp, i32, vp, i32, i32]; L.gz_block_dlpack.restype = vp
+    L.gz_exchange_select.argtypes = [vp, C.c_int]
     L.gz_comm_unique_id.argtypes = [vp]
     L.gz_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
     L.gz_gather_rows.argtypes = [vp, vp, i64, i32, vp, vp, C.c_int]
@@ -340,6 +341,10 @@ class Context:
                                                         n_docs, text_bytes, C.c_void_p(d_out) if d_out else None, capacity,
                                                         C.c_void_p(d_out_off), C.byref(total)))
         return total.value
+
+    def exchange_select(self, back: int):
+        """Exchange operations issued from now on belong to the encode call `back` calls before the latest one."""
+        self._check(self.lib.gz_exchange_select(self.handle, back))
 
     def compact_rows(self, d_rows, d_n_real, n_rows, row_len, d_out) -> int:
         total = C.c_int64()

@@ -215,6 +215,12 @@ void *gz_block_dlpack(gz_block *block, int32_t ndim, const int64_t *shape, int32
  * gz_comm_init with it; gz_gather_rows sends each rank's [n_rows, row_len] int32 device block to `root`,
  * which receives them back to back in rank order (grouped ncclSend/ncclRecv: each peer uses its own link). */
 int  gz_comm_unique_id(uint8_t id_out[128]);
+/* The exchange operations (gz_compact_rows, gz_gather_rows, gz_expand_rows) run on a stream of their own: they start
+ * when the encode call they belong to has finished and overlap the kernels of LATER encode calls; an encode call in
+ * turn waits for every exchange operation issued before it (it may overwrite the buffers they read).  By default they
+ * belong to the most recent encode call; gz_exchange_select(ctx, 1) makes the following ones belong to the call
+ * before it (double buffering: enqueue step k, then exchange step k-1).  gz_sync waits for both streams. */
+int  gz_exchange_select(gz_ctx *ctx, int back);
 int  gz_comm_init(gz_ctx *ctx, const uint8_t id[128], int rank, int world);
 int  gz_gather_rows(gz_ctx *ctx, const int32_t *send_dev, int64_t n_rows_local, int32_t row_len,
                     int32_t *recv_dev, const int64_t *rows_per_rank, int root);
