@@ -165,13 +165,14 @@ def main():
 
     kernel_ms = []
     last_totals = [None]
+    xbits = 16 if tok.vocab_size() <= 65536 and max(tok._special_ids()) < 65536 else 32   # ids are < len(encoder)
 
     def exchange(st):
         """The exchange step of one tokenized batch: every rank sends its rows WITHOUT the padding (row lengths + the
         rows' real entries, CSR form) straight to rank 0 over its own xGMI link (grouped ncclSend/ncclRecv).  Rank 0
         ends up with the ids of all documents; dense [N, L] ids / mask blocks are rebuilt from that on demand
         (gz_expand_rows, done once after the timed region for the check below; --expand-at-root puts it in every step)."""
-        total = ctx.compact_rows(st["ids"], st["nreal"], n, L, st["comp"])
+        total = ctx.compact_rows(st["ids"], st["nreal"], n, L, st["comp"], bits=xbits)
         t = torch.tensor([total], dtype=torch.int64, device="cuda")
         lst = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(lst, t)
@@ -183,9 +184,15 @@ def main():
             all_comp["cap"] = int(sum(totals) * 1.05) + 1024
             all_comp["ptr"] = ctx.alloc(4 * all_comp["cap"])
         ctx.gather_rows(st["nreal"], n, 1, d_all_nreal if rank == 0 else 0, rows_per_rank, 0)
-        ctx.gather_rows(st["comp"], total, 1, all_comp["ptr"], totals, 0)
+        # ranks' blocks are sent as int32 words: with 16-bit ids a block of `t` ids is (t + 1) // 2 words
+        words = [(t_ * xbits // 8 + 3) // 4 for t_ in totals]
+        ctx.gather_rows(st["comp"], words[rank], 1, all_comp["ptr"], words, 0)
         if rank == 0 and args.expand_at_root:
-            ctx.expand_rows(all_comp["ptr"], d_all_nreal, n * world, L, root_dense["ids"], root_dense["mask"])
+            w0 = 0
+            for q in range(world):                                 # every rank's block starts on a word boundary
+                ctx.expand_rows(all_comp["ptr"] + 4 * w0, d_all_nreal + 4 * n * q, n, L, root_dense["ids"] + 4 * n * L * q,
+                                root_dense["mask"] + 4 * n * L * q, bits=xbits)
+                w0 += words[q]
         last_totals[0] = totals
 
     root_dense = {}
@@ -340,7 +347,7 @@ def main():
             tot = last_totals[0]
             ok = all(int(nr_all[q * n:(q + 1) * n].sum()) == tot[q] for q in range(world))
             d_ci, d_cm = ctx.alloc(4 * n * L), ctx.alloc(4 * n * L)
-            ctx.expand_rows(all_comp["ptr"], d_all_nreal, n, L, d_ci, d_cm)
+            ctx.expand_rows(all_comp["ptr"], d_all_nreal, n, L, d_ci, d_cm, bits=xbits)
             ctx.sync()
             blk = np.empty((n, L), dtype=np.int32); ctx.d2h(blk, d_ci)
             mblk = np.empty((n, L), dtype=np.int32); ctx.d2h(mblk, d_cm)
@@ -369,8 +376,8 @@ def main():
                                    "5%% 121-400 words), max_len=%d pad+trunc, bundled vocab" % (n, L),
                        "docs_total": total_docs, "input_bytes_total": int(total_bytes),
                        "tokens_total": int(total_tokens),
-                       "sharding": "dp%d by documents; exchange = RCCL gatherv (grouped send/recv over direct xGMI links) of row lengths + unpadded ids (CSR) to rank 0, double-buffered under the next step's kernels%s" % (
-                           world, "" if gather or world == 1 else " DISABLED (--no-gather)") if world > 1 else "single GPU",
+                       "sharding": "dp%d by documents; exchange = RCCL gatherv (grouped send/recv over direct xGMI links) of row lengths + unpadded ids (CSR, %d-bit entries) to rank 0, double-buffered under the next step's kernels%s" % (
+                           world, xbits, "" if gather or world == 1 else " DISABLED (--no-gather)") if (world > 1 or gather) else "single GPU",
                        "inputs": "resident in HBM before the timed region"},
             "roofline": {"bound": "hbm",
                          "kernel": "the pipeline of one step, 9 launches on one stream: gz_brk, gz_classify, gz_scan32, gz_docw0, "

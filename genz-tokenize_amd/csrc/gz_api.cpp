@@ -1115,19 +1115,26 @@ void* gz_block_dlpack(gz_block* b, int32_t ndim, const int64_t* shape, int32_t d
 }
 
 // ---- compact rows for the exchange step -----------------------------------------------------------------------------
-int gz_compact_rows(gz_ctx* c, const int32_t* rows_dev, const int32_t* n_real_dev, int64_t n_rows, int32_t row_len,
-                    int32_t* out_dev, int64_t* total_host)
+namespace {
+bool ids_fit_16(gz_ctx* c)
+{
+    for (int32_t id : c->host.enc_ids) if (id < 0 || id > 0xFFFF) return false;
+    return true;
+}
+int compact_impl(gz_ctx* c, const int32_t* rows_dev, const int32_t* n_real_dev, int64_t n_rows, int32_t row_len, void* out_dev,
+                 int bits, int64_t* total_host)
 {
     if (!c || !rows_dev || !n_real_dev || !out_dev || !total_host || n_rows < 0 || row_len <= 0)
         return c ? fail(c, GZ_E_INVALID, "bad arguments") : GZ_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mu);
+    if (bits == 16 && (!c->have_tables || !ids_fit_16(c))) return fail(c, GZ_E_LIMIT, "the vocabulary has ids that do not fit 16 bits");
     HIPCHK(c, hipSetDevice(c->device));
     int rc;
     if ((rc = ensure(c, c->w_rowoff32, (size_t)(n_rows + 2) * 4))) return rc;
     uint32_t* off = (uint32_t*)c->w_rowoff32.p;
     if ((rc = x_begin(c))) return rc;
     gz_launch_row_offsets(n_real_dev, n_rows, off, c->xstream);
-    gz_launch_compact(rows_dev, off, n_rows, row_len, out_dev, c->xstream);
+    gz_launch_compact(rows_dev, off, n_rows, row_len, out_dev, bits, c->xstream);
     uint32_t total = 0;
     HIPCHK(c, hipMemcpyAsync(&total, off + n_rows, 4, hipMemcpyDeviceToHost, c->xstream));
     if ((rc = x_end(c))) return rc;
@@ -1136,9 +1143,8 @@ int gz_compact_rows(gz_ctx* c, const int32_t* rows_dev, const int32_t* n_real_de
     *total_host = total;
     return GZ_OK;
 }
-
-int gz_expand_rows(gz_ctx* c, const int32_t* compact_dev, const int32_t* n_real_dev, int64_t n_rows, int32_t row_len,
-                   int32_t* ids_dev, int32_t* mask_dev)
+int expand_impl(gz_ctx* c, const void* compact_dev, int bits, const int32_t* n_real_dev, int64_t n_rows, int32_t row_len,
+                int32_t* ids_dev, int32_t* mask_dev)
 {
     if (!c || !compact_dev || !n_real_dev || !ids_dev || !mask_dev || n_rows < 0 || row_len <= 0)
         return c ? fail(c, GZ_E_INVALID, "bad arguments") : GZ_E_INVALID;
@@ -1150,10 +1156,32 @@ int gz_expand_rows(gz_ctx* c, const int32_t* compact_dev, const int32_t* n_real_
     uint32_t* off = (uint32_t*)c->w_rowoff32.p;
     if ((rc = x_begin(c))) return rc;
     gz_launch_row_offsets(n_real_dev, n_rows, off, c->xstream);
-    gz_launch_expand(compact_dev, off, n_rows, row_len, c->dev.pad_id, ids_dev, mask_dev, c->xstream);
+    gz_launch_expand(compact_dev, bits, off, n_rows, row_len, c->dev.pad_id, ids_dev, mask_dev, c->xstream);
     if ((rc = x_end(c))) return rc;
     HIPCHK(c, hipGetLastError());
     return GZ_OK;
+}
+}  // namespace
+
+int gz_compact_rows(gz_ctx* c, const int32_t* rows_dev, const int32_t* n_real_dev, int64_t n_rows, int32_t row_len,
+                    int32_t* out_dev, int64_t* total_host)
+{
+    return compact_impl(c, rows_dev, n_real_dev, n_rows, row_len, out_dev, 32, total_host);
+}
+int gz_compact_rows16(gz_ctx* c, const int32_t* rows_dev, const int32_t* n_real_dev, int64_t n_rows, int32_t row_len,
+                      uint16_t* out_dev, int64_t* total_host)
+{
+    return compact_impl(c, rows_dev, n_real_dev, n_rows, row_len, out_dev, 16, total_host);
+}
+int gz_expand_rows(gz_ctx* c, const int32_t* compact_dev, const int32_t* n_real_dev, int64_t n_rows, int32_t row_len,
+                   int32_t* ids_dev, int32_t* mask_dev)
+{
+    return expand_impl(c, compact_dev, 32, n_real_dev, n_rows, row_len, ids_dev, mask_dev);
+}
+int gz_expand_rows16(gz_ctx* c, const uint16_t* compact_dev, const int32_t* n_real_dev, int64_t n_rows, int32_t row_len,
+                     int32_t* ids_dev, int32_t* mask_dev)
+{
+    return expand_impl(c, compact_dev, 16, n_real_dev, n_rows, row_len, ids_dev, mask_dev);
 }
 
 // ---- host-only table build (diagnostics, offline checks; no GPU) ------------------------------------------------------

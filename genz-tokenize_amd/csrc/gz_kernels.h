@@ -65,8 +65,8 @@ void gz_launch_pipeline_text(const GzDeviceTables* T_dev, const GzTextBufs& X, i
                              int32_t* long_flag /* device int, zeroed by the caller */, hipStream_t s);
 void gz_launch_pick(const int64_t* off, const int64_t* off2, int64_t n_docs, int nsub, int64_t* out /* 2*(nsub+1) */, hipStream_t s);
 void gz_launch_row_offsets(const int32_t* n_real, int64_t n_rows, uint32_t* off, hipStream_t s);
-void gz_launch_compact(const int32_t* rows, const uint32_t* off, int64_t n_rows, int32_t row_len, int32_t* out, hipStream_t s);
-void gz_launch_expand(const int32_t* compact, const uint32_t* off, int64_t n_rows, int32_t row_len, int32_t pad_id, int32_t* ids,
+void gz_launch_compact(const int32_t* rows, const uint32_t* off, int64_t n_rows, int32_t row_len, void* out, int bits /* 32 | 16 */, hipStream_t s);
+void gz_launch_expand(const void* compact, int bits, const uint32_t* off, int64_t n_rows, int32_t row_len, int32_t pad_id, int32_t* ids,
                       int32_t* mask, hipStream_t s);
 void gz_launch_assemble(const GzDeviceTables* T_dev, const GzAsmArgs& A, hipStream_t s);
 

@@ -26,7 +26,7 @@ SYMBOLS = [
     "gz_vocab_entry", "gz_merge_entry", "gz_encode_batch", "gz_encode_batch_device", "gz_sync",
     "gz_word_token_counts", "gz_bpe_word", "gz_symbol_utf8", "gz_device_alloc", "gz_device_free", "gz_memcpy_h2d", "gz_memcpy_d2h",
     "gz_timing", "gz_decoder_snapshot", "gz_decode_batch", "gz_decode_batch_device", "gz_preprocess_batch",
-    "gz_preprocess_batch_device", "gz_block_create", "gz_block_release", "gz_block_dlpack", "gz_exchange_select", "gz_comm_unique_id", "gz_comm_init", "gz_gather_rows", "gz_compact_rows", "gz_expand_rows",
+    "gz_preprocess_batch_device", "gz_block_create", "gz_block_release", "gz_block_dlpack", "gz_exchange_select", "gz_comm_unique_id", "gz_comm_init", "gz_gather_rows", "gz_compact_rows", "gz_expand_rows", "gz_compact_rows16", "gz_expand_rows16",
     "gz_host_tables_create", "gz_host_tables_destroy", "gz_host_tables_array", "gz_host_tables_vocab_entry",
     "gz_host_tables_merge_entry", "gz_host_tables_symbol",
 ]
@@ -86,6 +86,8 @@ def load_library():
     L.gz_gather_rows.argtypes = [vp, vp, i64, i32, vp, vp, C.c_int]
     L.gz_compact_rows.argtypes = [vp, vp, vp, i64, i32, vp, P(i64)]
     L.gz_expand_rows.argtypes = [vp, vp, vp, i64, i32, vp, vp]
+    L.gz_compact_rows16.argtypes = [vp, vp, vp, i64, i32, vp, P(i64)]
+    L.gz_expand_rows16.argtypes = [vp, vp, vp, i64, i32, vp, vp]
     L.gz_host_tables_create.argtypes = [vp, sz, vp, sz, P(C.c_char_p), P(vp)]
     L.gz_host_tables_destroy.argtypes = [vp]; L.gz_host_tables_destroy.restype = None
     L.gz_host_tables_array.argtypes = [vp, C.c_int, P(vp), P(i64)]
@@ -346,15 +348,16 @@ class Context:
         """Exchange operations issued from now on belong to the encode call `back` calls before the latest one."""
         self._check(self.lib.gz_exchange_select(self.handle, back))
 
-    def compact_rows(self, d_rows, d_n_real, n_rows, row_len, d_out) -> int:
+    def compact_rows(self, d_rows, d_n_real, n_rows, row_len, d_out, bits: int = 32) -> int:
+        """Rows without their padding, back to back, as int32 (bits=32) or uint16 (bits=16) entries; returns the count."""
         total = C.c_int64()
-        self._check(self.lib.gz_compact_rows(self.handle, C.c_void_p(d_rows), C.c_void_p(d_n_real), n_rows, row_len,
-                                             C.c_void_p(d_out), C.byref(total)))
+        fn = self.lib.gz_compact_rows16 if bits == 16 else self.lib.gz_compact_rows
+        self._check(fn(self.handle, C.c_void_p(d_rows), C.c_void_p(d_n_real), n_rows, row_len, C.c_void_p(d_out), C.byref(total)))
         return total.value
 
-    def expand_rows(self, d_compact, d_n_real, n_rows, row_len, d_ids, d_mask):
-        self._check(self.lib.gz_expand_rows(self.handle, C.c_void_p(d_compact), C.c_void_p(d_n_real), n_rows, row_len,
-                                            C.c_void_p(d_ids), C.c_void_p(d_mask)))
+    def expand_rows(self, d_compact, d_n_real, n_rows, row_len, d_ids, d_mask, bits: int = 32):
+        fn = self.lib.gz_expand_rows16 if bits == 16 else self.lib.gz_expand_rows
+        self._check(fn(self.handle, C.c_void_p(d_compact), C.c_void_p(d_n_real), n_rows, row_len, C.c_void_p(d_ids), C.c_void_p(d_mask)))
 
     def gather_rows(self, d_send, n_rows_local, row_len, d_recv, rows_per_rank, root=0):
         rpr = np.ascontiguousarray(rows_per_rank, dtype=np.int64)

@@ -235,6 +235,12 @@ int  gz_compact_rows(gz_ctx *ctx, const int32_t *rows_dev, const int32_t *n_real
                      int32_t *out_dev, int64_t *total_host);
 int  gz_expand_rows(gz_ctx *ctx, const int32_t *compact_dev, const int32_t *n_real_dev, int64_t n_rows, int32_t row_len,
                     int32_t *ids_dev, int32_t *mask_dev);
+/* The same with 16-bit entries (half the bytes on the link): only when every id of the loaded vocabulary fits 16 bits
+ * (GZ_E_LIMIT otherwise); lossless. */
+int  gz_compact_rows16(gz_ctx *ctx, const int32_t *rows_dev, const int32_t *n_real_dev, int64_t n_rows, int32_t row_len,
+                       uint16_t *out_dev, int64_t *total_host);
+int  gz_expand_rows16(gz_ctx *ctx, const uint16_t *compact_dev, const int32_t *n_real_dev, int64_t n_rows, int32_t row_len,
+                      int32_t *ids_dev, int32_t *mask_dev);
 
 #ifdef __cplusplus
 }

@@ -326,8 +326,32 @@ def test_compact_expand_round_trip(tok, sampler):
     i2 = np.empty_like(ids); m2 = np.empty_like(mask)
     ctx.d2h(i2, d_i2); ctx.d2h(m2, d_m2)
     assert np.array_equal(i2, ids) and np.array_equal(m2, mask)
+    # 16-bit entries (the bundled vocabulary's ids fit): half the bytes, same rows back
+    total16 = ctx.compact_rows(d_ids, d_nr, n, L, d_comp, bits=16)
+    assert total16 == total
+    comp16 = np.empty(total, dtype=np.uint16); ctx.d2h(comp16, d_comp)
+    assert np.array_equal(comp16.astype(np.int32), comp)
+    ctx.expand_rows(d_comp, d_nr, n, L, d_i2, d_m2, bits=16)
+    ctx.sync()
+    ctx.d2h(i2, d_i2); ctx.d2h(m2, d_m2)
+    assert np.array_equal(i2, ids) and np.array_equal(m2, mask)
     for p in (d_ids, d_nr, d_comp, d_i2, d_m2):
         ctx.free(p)
+
+
+def test_compact16_refuses_wide_ids(sampler, tmp_path):
+    """A vocabulary with ids above 65535 cannot use the 16-bit exchange form."""
+    from genz_tokenize import Tokenize, _native
+    v, b = corpus.custom_tables()                      # 100 k entries
+    (tmp_path / "v").write_bytes(v); (tmp_path / "b").write_bytes(b)
+    t = Tokenize.fromFile(str(tmp_path / "v"), str(tmp_path / "b"))
+    t._sync_tables()
+    ctx = t._ctx
+    d = ctx.alloc(1024)
+    with pytest.raises(_native.GzError) as e:
+        ctx.compact_rows(d, d, 1, 4, d, bits=16)
+    assert e.value.code == _native.GZ_E_LIMIT
+    ctx.free(d)
 
 
 def test_g6_decode_batch(tok, tmp_path):
