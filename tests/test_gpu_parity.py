@@ -451,3 +451,67 @@ def test_device_handoff_dlpack():
     r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "handoff_child.py")],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "HANDOFF OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])
+def test_random_tables_fuzz(seed, tmp_path):
+    """Random merge tables over a tiny alphabet (deep merge chains, overlapping pairs like 'a a', the same string
+    reachable through different merges, literal '</w>' / '@@' pieces, missing vocabulary entries) and random texts with
+    words of 1..300 symbols, against the plain-C restatement -- every merge kernel width, both word-table modes."""
+    import random
+    import gz_oracle_c as OC
+    from genz_tokenize import Tokenize
+    r = random.Random(1000 + seed)
+    alphabet = list("ab") + r.sample(list("cdeghk_"), 3) + r.sample(["\u00e2", "\u1ec7", "\u0111", "\U0001F600", "\u4e2d"], 2)
+    if seed % 2 == 0:
+        alphabet += ["<", "/", "w", ">", "@"]
+    syms = list(alphabet)
+    finals = [a + "</w>" for a in alphabet]
+    merges = []
+    for _ in range(r.choice([40, 150, 600, 1500])):
+        left = r.choice(syms)
+        if r.random() < 0.35:
+            right = r.choice(finals); new = left + right; finals.append(new)
+        else:
+            right = r.choice(syms); new = left + right; syms.append(new)
+        if len(new) > 40:
+            continue
+        merges.append(left + " " + right)
+    if r.random() < 0.5:
+        merges.insert(0, "#version: 0.2")
+    if seed == 3:
+        merges += merges[5:25]                                   # duplicate lines: the later rank wins
+    bpe = ("\n".join(merges) + "\n").encode("utf-8")
+    words = set()
+    for x in syms:
+        if r.random() < 0.8: words.add(x + "@@")
+    for x in finals:
+        if r.random() < 0.8: words.add(x[:-4])
+    words = sorted(words); r.shuffle(words)
+    vocab = "".join("%s %d\n" % (w, r.randint(1, 99)) for w in words).encode("utf-8")
+    (tmp_path / "v").write_bytes(vocab); (tmp_path / "b").write_bytes(bpe)
+    tok = Tokenize.fromFile(str(tmp_path / "v"), str(tmp_path / "b"))
+    co = OC.COracle(vocab, bpe)
+
+    def word():
+        n = r.choice([1, 1, 2, 3, 4, 5, 6, 7, 8, 9, 12, 15, 16, 17, 20, 31, 32, 33, 50, 64, 65, 100, 300])
+        return "".join(r.choice(alphabet) for _ in range(n))
+    docs = []
+    for _ in range(1500):
+        k = r.choice([0, 1, 2, 5, 10, 30])
+        docs.append("".join(word() + r.choice([" ", " ", "  ", "\n", "\n ", "\t", "\u3000"]) for _ in range(k)))
+    text, toff = OC._pack(docs)
+    text = np.ascontiguousarray(text)                        # (one spare byte at the end; offsets do not cover it)
+    for ml, pad, tr in ((None, True, True), (24, True, True)):
+        ids, mask, _, _, row, _, _ = co.call_packed(text, toff, max_len=ml, padding=pad, truncation=tr)
+        lens = np.diff(row)
+        for wt in (True, False):
+            out = tok.encode_packed(text, toff, max_len=ml, padding=pad, truncation=tr, word_table=wt)
+            ro = np.asarray(out["row_off"], np.int64)
+            assert np.array_equal(np.diff(ro), lens), (seed, ml, wt)
+            got = _gather(out["input_ids"].reshape(-1), ro[:-1], lens)
+            if not np.array_equal(got, ids[:row[-1]]):
+                bad = int(np.nonzero(got != ids[:row[-1]])[0][0])
+                d = int(np.searchsorted(row, bad, side="right") - 1)
+                raise AssertionError((seed, ml, wt, "doc", d, docs[d][:200], got[row[d]:row[d + 1]][:40], ids[row[d]:row[d + 1]][:40]))
+            assert np.array_equal(_gather(out["attention_mask"].reshape(-1), ro[:-1], lens), mask[:row[-1]])
