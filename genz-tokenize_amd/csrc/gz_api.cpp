@@ -115,6 +115,7 @@ struct gz_ctx {
     bool dec_unk_set = false;
     DBuf t_dec_entries, t_dec_bytes, w_dec_ids, w_dec_roff, w_dec_rb, w_dec_ooff, w_dec_out;
     DBuf w_pp[2], w_ppoff[2], w_pplen, w_ppaux, w_pp_in, w_pp_inoff;      // text pre-pass
+    DBuf w_tiny[2][2];                                                     // texts of fewer than 16 bytes, see encode_device_locked
     bool building_words = false;         // the whole-word table is being built: ignore diagnostics
     bool no_words_env = false;           // GZ_WORD_TABLE=0 in the environment
 };
@@ -334,6 +335,16 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
             if (Bt < 0) return fail(c, GZ_E_INVALID, "offsets are not non-decreasing");
             if (Bt >= (int64_t)0xFFFF0000ll) return fail(c, GZ_E_LIMIT, "a batch of 4 GiB or more of text must be split");
             X.tb = (tx ? pair : text) + cut[k];
+            if (Bt > 0 && Bt < 16) {
+                // the kernels read the 16 bytes that END at the last byte of the text (load16 / load4_tail move a load
+                // back instead of running past B): give a tiny text 16 bytes of lead-in and zeroed slack behind it
+                DBuf& tiny = c->w_tiny[k & 1][tx];
+                int rc3;
+                if ((rc3 = ensure(c, tiny, 64))) return rc3;
+                HIPCHK(c, hipMemsetAsync(tiny.p, 0, 64, c->stream));
+                HIPCHK(c, hipMemcpyAsync((uint8_t*)tiny.p + 16, X.tb, (size_t)Bt, hipMemcpyDeviceToDevice, c->stream));
+                X.tb = (const uint8_t*)tiny.p + 16;
+            }
             X.off = (tx ? pair_off : text_off) + lo;
             X.B = Bt;
             X.nblk = Bt / 4096 + 1;
@@ -515,6 +526,7 @@ void gz_destroy(gz_ctx* c)
     if (c->xstream) hipStreamDestroy(c->xstream);
     if (c->h_pick) hipHostFree(c->h_pick);
     release(c->w_pick); release(c->w_rowoff32);
+    for (auto& t2 : c->w_tiny) for (auto& t : t2) release(t);
     for (DBuf* b : {&c->w_pp[0], &c->w_pp[1], &c->w_ppoff[0], &c->w_ppoff[1], &c->w_pplen, &c->w_ppaux, &c->w_pp_in, &c->w_pp_inoff}) release(*b);
     for (DBuf* b : {&c->t_dec_entries, &c->t_dec_bytes, &c->w_dec_ids, &c->w_dec_roff, &c->w_dec_rb, &c->w_dec_ooff, &c->w_dec_out}) release(*b);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
