@@ -138,6 +138,7 @@ def main():
     # ---- workload (untimed): synthetic documents of BASELINE configs[2] (N=1) / configs[3] shards (N>1) ----------
     seed = 3 if world == 1 else 100 + rank
     text, offs, L = corpus.config_corpus(3, n_docs=args.docs, seed=seed)
+    offs = np.ascontiguousarray(offs, dtype=np.int64)
     n = len(offs) - 1
     in_bytes = int(offs[-1])
     d_text = ctx.alloc(in_bytes + 64); ctx.h2d(d_text, text)
@@ -203,7 +204,7 @@ def main():
         """k_steps tokenization steps; with an exchange, step k's kernels overlap the exchange of step k-1."""
         for k in range(k_steps):
             st = sets[k % nset]
-            ctx.encode_device(d_text, d_off, 0, 0, n, L, flags, n * L, st["ids"], st["mask"], d_n_real=st["nreal"])
+            ctx.encode_device(d_text, d_off, 0, 0, n, L, flags, n * L, st["ids"], st["mask"], d_n_real=st["nreal"], h_text_off=offs)
             if gather:
                 if k > 0:
                     ctx.exchange_select(1)

@@ -94,7 +94,7 @@ struct gz_ctx {
     int rank = 0, world = 1;
 
     DBuf t_words2, t_words0;
-    struct TextWs { DBuf brk, st, en, blkcnt, docw0, wtok, waux, mtok, mlist, blkmiss, blklong; } tw[2][2];   // [slot][text]
+    struct TextWs { DBuf brk, st, en, blkcnt, docw0, wtok, waux, mtok, mlist, blkmiss, blklong, tilecnt; } tw[2][2];   // [slot][text]
     hipStream_t stream2 = nullptr;       // sub-batches alternate between the two streams
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // exchange step (compact / gather / expand) on its own stream, so that it overlaps the next call's kernels
@@ -355,12 +355,13 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
                 (rc2 = ensure(c, W.blkcnt, (size_t)(X.nblk + 2) * 4)) || (rc2 = ensure(c, W.docw0, (size_t)(S2.n_docs + 2) * 4)) ||
                 (rc2 = ensure(c, W.wtok, (size_t)wmax * 4)) || (rc2 = ensure(c, W.waux, (size_t)wmax * 4)) ||
                 (rc2 = ensure(c, W.mtok, (size_t)(Bt + 32) * 4)) || (rc2 = ensure(c, W.mlist, (size_t)wmax * 4)) ||
-                (rc2 = ensure(c, W.blkmiss, (size_t)(X.nblk + 2) * 4)) || (rc2 = ensure(c, W.blklong, (size_t)(X.nblk + 2) * 4)))
+                (rc2 = ensure(c, W.blkmiss, (size_t)(X.nblk + 2) * 4)) || (rc2 = ensure(c, W.blklong, (size_t)(X.nblk + 2) * 4)) ||
+                (rc2 = ensure(c, W.tilecnt, (size_t)(X.nblk + 2) * 8)))
                 return rc2;
             X.brk = (uint16_t*)W.brk.p; X.st = (uint16_t*)W.st.p; X.en = (uint16_t*)W.en.p;
             X.blkcnt = (uint32_t*)W.blkcnt.p; X.docw0 = (uint32_t*)W.docw0.p;
             X.wtok = (uint32_t*)W.wtok.p; X.waux = (uint32_t*)W.waux.p; X.mtok = (int32_t*)W.mtok.p;
-            X.mlist = (uint32_t*)W.mlist.p; X.blkmiss = (uint32_t*)W.blkmiss.p; X.blklong = (uint32_t*)W.blklong.p;
+            X.mlist = (uint32_t*)W.mlist.p; X.blkmiss = (uint32_t*)W.blkmiss.p; X.blklong = (uint32_t*)W.blklong.p; X.tilecnt = (uint16_t*)W.tilecnt.p;
         }
     }
     if (!dense) {
@@ -535,7 +536,7 @@ void gz_destroy(gz_ctx* c)
                     &c->w_nreal, &c->w_status, &c->w_raw, &c->w_arena, &c->w_flags, &c->w_word, &c->w_wordout})
         release(*b);
     for (auto& slot : c->tw) for (auto& t : slot)
-        for (DBuf* b : {&t.brk, &t.st, &t.en, &t.blkcnt, &t.docw0, &t.wtok, &t.waux, &t.mtok, &t.mlist, &t.blkmiss, &t.blklong}) release(*b);
+        for (DBuf* b : {&t.brk, &t.st, &t.en, &t.blkcnt, &t.docw0, &t.wtok, &t.waux, &t.mtok, &t.mlist, &t.blkmiss, &t.blklong, &t.tilecnt}) release(*b);
     for (auto& ev : c->ev) if (ev) hipEventDestroy(ev);
     if (c->h_flags) hipHostFree(c->h_flags);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -639,6 +640,22 @@ int gz_encode_batch_device(gz_ctx* c, const uint8_t* text, const int64_t* text_o
     HIPCHK(c, hipSetDevice(c->device));
     return encode_device_locked(c, text, text_off, pair, pair_off, n_docs, max_len, flags, capacity, input_ids,
                                 attention_mask, token_type_ids, sequence_id, row_off, pair_len, n_real, status, nullptr, nullptr);
+}
+
+int gz_encode_batch_device_h(gz_ctx* c, const uint8_t* text, const int64_t* text_off, const uint8_t* pair,
+                             const int64_t* pair_off, int64_t n_docs, int32_t max_len, uint32_t flags, int64_t capacity,
+                             int32_t* input_ids, int32_t* attention_mask, int32_t* token_type_ids, int32_t* sequence_id,
+                             int64_t* row_off, int32_t* pair_len, int32_t* n_real, int32_t* status,
+                             const int64_t* text_off_host, const int64_t* pair_off_host)
+{
+    if (!c) return GZ_E_INVALID;
+    if (!text_off_host || ((pair_off != nullptr) != (pair_off_host != nullptr)))
+        return fail(c, GZ_E_INVALID, "host copies of the offsets are required for every text");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    return encode_device_locked(c, text, text_off, pair, pair_off, n_docs, max_len, flags, capacity, input_ids,
+                                attention_mask, token_type_ids, sequence_id, row_off, pair_len, n_real, status,
+                                text_off_host, pair_off_host);
 }
 
 int gz_sync(gz_ctx* c)

@@ -23,7 +23,7 @@ GZ_PP_HTML, GZ_PP_UNICODE, GZ_PP_PUNCT, GZ_PP_EMOJI, GZ_PP_URL = 1, 2, 3, 4, 5
 # every symbol include/genz_tokenize.h declares (tests/test_abi.py checks the export list against the header)
 SYMBOLS = [
     "gz_version", "gz_create", "gz_destroy", "gz_last_error", "gz_load_tables", "gz_table_info",
-    "gz_vocab_entry", "gz_merge_entry", "gz_encode_batch", "gz_encode_batch_device", "gz_sync",
+    "gz_vocab_entry", "gz_merge_entry", "gz_encode_batch", "gz_encode_batch_device", "gz_encode_batch_device_h", "gz_sync",
     "gz_word_token_counts", "gz_bpe_word", "gz_symbol_utf8", "gz_device_alloc", "gz_device_free", "gz_memcpy_h2d", "gz_memcpy_d2h",
     "gz_timing", "gz_decoder_snapshot", "gz_decode_batch", "gz_decode_batch_device", "gz_preprocess_batch",
     "gz_preprocess_batch_device", "gz_block_create", "gz_block_release", "gz_block_dlpack", "gz_exchange_select", "gz_comm_unique_id", "gz_comm_init", "gz_gather_rows", "gz_compact_rows", "gz_expand_rows", "gz_compact_rows16", "gz_expand_rows16",
@@ -63,6 +63,7 @@ def load_library():
     enc = [vp, vp, vp, vp, vp, i64, i32, u32, i64, vp, vp, vp, vp, vp, vp, vp, vp]
     L.gz_encode_batch.argtypes = enc
     L.gz_encode_batch_device.argtypes = enc
+    L.gz_encode_batch_device_h.argtypes = enc + [vp, vp]
     L.gz_sync.argtypes = [vp]
     L.gz_word_token_counts.argtypes = [vp, C.c_int, vp, i64, vp, P(i64)]
     L.gz_bpe_word.argtypes = [vp, vp, i64, vp, i64]; L.gz_bpe_word.restype = i64
@@ -265,14 +266,19 @@ class Context:
 
     def encode_device(self, d_text, d_text_off, d_pair, d_pair_off, n_docs, max_len, flags, capacity,
                       d_ids, d_mask, d_tt=None, d_seq=None, d_row_off=None, d_pair_len=None, d_n_real=None,
-                      d_status=None):
+                      d_status=None, h_text_off=None, h_pair_off=None):
+        """Enqueue one call on device-resident buffers.  h_text_off / h_pair_off: optional host copies (int64 numpy) of
+        the offsets; with them the library does not read the batch's byte sizes back from the device first."""
         vp = C.c_void_p
-        self._check(self.lib.gz_encode_batch_device(
-            self.handle, vp(d_text), vp(d_text_off), vp(d_pair) if d_pair else None,
-            vp(d_pair_off) if d_pair_off else None, n_docs, max_len, flags, capacity, vp(d_ids), vp(d_mask),
-            vp(d_tt) if d_tt else None, vp(d_seq) if d_seq else None, vp(d_row_off) if d_row_off else None,
-            vp(d_pair_len) if d_pair_len else None, vp(d_n_real) if d_n_real else None,
-            vp(d_status) if d_status else None))
+        args = [self.handle, vp(d_text), vp(d_text_off), vp(d_pair) if d_pair else None,
+                vp(d_pair_off) if d_pair_off else None, n_docs, max_len, flags, capacity, vp(d_ids), vp(d_mask),
+                vp(d_tt) if d_tt else None, vp(d_seq) if d_seq else None, vp(d_row_off) if d_row_off else None,
+                vp(d_pair_len) if d_pair_len else None, vp(d_n_real) if d_n_real else None,
+                vp(d_status) if d_status else None]
+        if h_text_off is not None:
+            self._check(self.lib.gz_encode_batch_device_h(*args, _ptr(h_text_off), _ptr(h_pair_off)))
+        else:
+            self._check(self.lib.gz_encode_batch_device(*args))
 
     def sync(self):
         self._check(self.lib.gz_sync(self.handle))

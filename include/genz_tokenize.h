@@ -118,6 +118,14 @@ int  gz_encode_batch_device(gz_ctx *ctx,
                             int32_t *input_ids, int32_t *attention_mask,
                             int32_t *token_type_ids, int32_t *sequence_id,
                             int64_t *row_off, int32_t *pair_len, int32_t *n_real, int32_t *status);
+/* The same when the caller also has the offsets on the host (it usually built them there): the library then knows the
+ * byte sizes of the batch without reading them back from the device, i.e. without a host round trip before the
+ * kernels are enqueued. */
+int  gz_encode_batch_device_h(gz_ctx *ctx, const uint8_t *text, const int64_t *text_off, const uint8_t *pair,
+                              const int64_t *pair_off, int64_t n_docs, int32_t max_len, uint32_t flags, int64_t capacity,
+                              int32_t *input_ids, int32_t *attention_mask, int32_t *token_type_ids, int32_t *sequence_id,
+                              int64_t *row_off, int32_t *pair_len, int32_t *n_real, int32_t *status,
+                              const int64_t *text_off_host, const int64_t *pair_off_host);
 int  gz_sync(gz_ctx *ctx);
 
 /* Token count of every word of the LAST encode call (for `return_offset=True`, tokenize.py:105,111-117,225-244):
