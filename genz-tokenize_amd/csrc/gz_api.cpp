@@ -94,7 +94,7 @@ struct gz_ctx {
     int rank = 0, world = 1;
 
     DBuf t_words2, t_words0;
-    struct TextWs { DBuf brk, st, en, blkcnt, docw0, wtok, waux, mtok, mlist, blkmiss, blklong, tilecnt; } tw[2][2];   // [slot][text]
+    struct TextWs { DBuf brk, st, en, blkcnt, docw0, wtok, waux, mtok, mlist, blkmiss, blklong, tilecnt, wlist; } tw[2][2];   // [slot][text]
     hipStream_t stream2 = nullptr;       // sub-batches alternate between the two streams
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // exchange step (compact / gather / expand) on its own stream, so that it overlaps the next call's kernels
@@ -356,12 +356,12 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
                 (rc2 = ensure(c, W.wtok, (size_t)wmax * 4)) || (rc2 = ensure(c, W.waux, (size_t)wmax * 4)) ||
                 (rc2 = ensure(c, W.mtok, (size_t)(Bt + 32) * 4)) || (rc2 = ensure(c, W.mlist, (size_t)wmax * 4)) ||
                 (rc2 = ensure(c, W.blkmiss, (size_t)(X.nblk + 2) * 4)) || (rc2 = ensure(c, W.blklong, (size_t)(X.nblk + 2) * 4)) ||
-                (rc2 = ensure(c, W.tilecnt, (size_t)(X.nblk + 2) * 8)))
+                (rc2 = ensure(c, W.tilecnt, (size_t)(X.nblk + 2) * 8)) || (rc2 = ensure(c, W.wlist, (size_t)(wmax + 2) * 4)))
                 return rc2;
             X.brk = (uint16_t*)W.brk.p; X.st = (uint16_t*)W.st.p; X.en = (uint16_t*)W.en.p;
             X.blkcnt = (uint32_t*)W.blkcnt.p; X.docw0 = (uint32_t*)W.docw0.p;
             X.wtok = (uint32_t*)W.wtok.p; X.waux = (uint32_t*)W.waux.p; X.mtok = (int32_t*)W.mtok.p;
-            X.mlist = (uint32_t*)W.mlist.p; X.blkmiss = (uint32_t*)W.blkmiss.p; X.blklong = (uint32_t*)W.blklong.p; X.tilecnt = (uint16_t*)W.tilecnt.p;
+            X.mlist = (uint32_t*)W.mlist.p; X.blkmiss = (uint32_t*)W.blkmiss.p; X.blklong = (uint32_t*)W.blklong.p; X.tilecnt = (uint16_t*)W.tilecnt.p; X.wlist = (uint32_t*)W.wlist.p;
         }
     }
     if (!dense) {
@@ -536,7 +536,7 @@ void gz_destroy(gz_ctx* c)
                     &c->w_nreal, &c->w_status, &c->w_raw, &c->w_arena, &c->w_flags, &c->w_word, &c->w_wordout})
         release(*b);
     for (auto& slot : c->tw) for (auto& t : slot)
-        for (DBuf* b : {&t.brk, &t.st, &t.en, &t.blkcnt, &t.docw0, &t.wtok, &t.waux, &t.mtok, &t.mlist, &t.blkmiss, &t.blklong, &t.tilecnt}) release(*b);
+        for (DBuf* b : {&t.brk, &t.st, &t.en, &t.blkcnt, &t.docw0, &t.wtok, &t.waux, &t.mtok, &t.mlist, &t.blkmiss, &t.blklong, &t.tilecnt, &t.wlist}) release(*b);
     for (auto& ev : c->ev) if (ev) hipEventDestroy(ev);
     if (c->h_flags) hipHostFree(c->h_flags);
     if (c->stream) hipStreamDestroy(c->stream);

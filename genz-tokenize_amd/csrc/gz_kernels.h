@@ -49,6 +49,7 @@ struct GzTextBufs {              // one text (A or B) of a batch and its per-cal
     uint32_t* mlist;             // [words] the misses of block b, compact, at mlist[blkcnt[b] ...]
     uint32_t* blkmiss;           // [nblk] number of misses per block
     uint32_t* blklong;           // [nblk] block holds a word for gz_long_kernel (zeroed per call)
+    uint32_t* wlist;             // [0] count, then the words (indices) that need 32 or 64 lanes (zeroed count per call)
     uint16_t* tilecnt;           // [4 * nblk] word starts of the block that lie before each of its four 1-KiB tiles
     int32_t* mtok;               // [B+16]
 };
