@@ -17,7 +17,6 @@ namespace {
 constexpr int WAVE = 64;
 constexpr int WPB = GZ_WAVES_PER_BLOCK;      // waves per workgroup of the small kernels (finalize, pair)
 constexpr int TILE = 1024;                   // bytes classified per tile: 16 per lane
-constexpr int MAXSYM = 16;                   // symbols of the 16-lanes-per-word merge pass
 constexpr int MAXWORDS = TILE / 2 + 1;       // a word needs >= 1 byte + >= 1 whitespace byte
 constexpr int GMAX = GZ_MAX_DOCS_PER_WAVE;   // documents per wave of the assemble kernel
 
@@ -172,12 +171,6 @@ __device__ __forceinline__ void emit_at(const Emit& E, int pos, int32_t id)
         if (E.mask) E.mask[pos] = id != E.pad_id ? 1 : 0;
         if (E.pad_hit && id == E.pad_id) *E.pad_hit = 1;
     }
-}
-
-__device__ __forceinline__ void emit_uniform(Emit& E, int32_t id, int lane)
-{
-    if (lane == 0) emit_at(E, E.ntok, id);
-    E.ntok += 1;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
