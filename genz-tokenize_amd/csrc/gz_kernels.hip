@@ -112,16 +112,21 @@ __device__ __forceinline__ uint32_t row16_min(uint32_t v)
 // tuple(token) / word[-1] + "</w>"  (tokenize.py:63-64): code point -> initial symbol
 __device__ __forceinline__ uint32_t initial_symbol(const GzDeviceTables& T, uint32_t cp, bool last)
 {
+    // (the table pointers come out of a struct in memory: say that they are global, or every lookup is a flat load)
+    typedef unsigned __attribute__((ext_vector_type(2))) v2u;
+    typedef unsigned __attribute__((ext_vector_type(4))) v4u;
+    typedef const v2u __attribute__((address_space(1)))* bmp_t;          // GzCpSyms  {plain, final_}
+    typedef const v4u __attribute__((address_space(1)))* astral_t;       // GzAstral  {cp, plain, final_, pad}
     uint32_t s = GZ_NO_SYMBOL;
     if (cp < 0x10000u) {
-        GzCpSyms e = T.bmp[cp];
-        s = last ? e.final_ : e.plain;
+        const v2u e = ((bmp_t)T.bmp)[cp];
+        s = last ? e.y : e.x;
     } else if (T.astral != nullptr) {
         uint32_t h = gz_cp_hash(cp) & T.astral_mask;
         for (;;) {
-            GzAstral e = T.astral[h];
-            if (e.cp == cp) { s = last ? e.final_ : e.plain; break; }
-            if (e.cp == GZ_NO_SYMBOL) break;
+            const v4u e = ((astral_t)T.astral)[h];
+            if (e.x == cp) { s = last ? e.z : e.y; break; }
+            if (e.x == GZ_NO_SYMBOL) break;
             h = (h + 1) & T.astral_mask;
         }
     }
@@ -131,9 +136,11 @@ __device__ __forceinline__ uint32_t initial_symbol(const GzDeviceTables& T, uint
 // encoder.get(piece, encoder.get(unk))  (tokenize.py:120-121)
 __device__ __forceinline__ int32_t token_id(const GzDeviceTables& T, uint32_t s, bool final_piece)
 {
+    typedef int __attribute__((ext_vector_type(2))) v2i;
+    typedef const v2i __attribute__((address_space(1)))* symids_t;       // GzSymIds  {nonfinal, final_}
     if (s & GZ_SYM_UNKNOWN) return T.unk_id;
-    GzSymIds e = T.sym_ids[s];
-    return final_piece ? e.final_ : e.nonfinal;
+    const v2i e = ((symids_t)T.sym_ids)[s];
+    return final_piece ? e.y : e.x;
 }
 
 // Structural UTF-8 decode of the code point whose lead byte is at index i; never reads at or past `end`.
