@@ -115,7 +115,7 @@ struct gz_ctx {
     bool dec_unk_set = false;
     DBuf t_dec_entries, t_dec_bytes, w_dec_ids, w_dec_roff, w_dec_rb, w_dec_ooff, w_dec_out;
     DBuf w_pp[2], w_ppoff[2], w_pplen, w_ppaux, w_pp_in, w_pp_inoff;      // text pre-pass
-    DBuf w_tiny[2][2];                                                     // texts of fewer than 16 bytes, see encode_device_locked
+    DBuf w_tiny[8][2];                                                     // texts of fewer than 16 bytes, see encode_device_locked
     bool building_words = false;         // the whole-word table is being built: ignore diagnostics
     bool no_words_env = false;           // GZ_WORD_TABLE=0 in the environment
 };
@@ -338,7 +338,7 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
             if (Bt > 0 && Bt < 16) {
                 // the kernels read the 16 bytes that END at the last byte of the text (load16 / load4_tail move a load
                 // back instead of running past B): give a tiny text 16 bytes of lead-in and zeroed slack behind it
-                DBuf& tiny = c->w_tiny[k & 1][tx];
+                DBuf& tiny = c->w_tiny[k & 7][tx];                          // (one per sub-batch: they are filled before any kernel runs)
                 int rc3;
                 if ((rc3 = ensure(c, tiny, 64))) return rc3;
                 HIPCHK(c, hipMemsetAsync(tiny.p, 0, 64, c->stream));
