@@ -33,13 +33,13 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 # HBM bytes per step (all kernels of the pipeline) on the default workload, from the PMC passes kept in
-# profiles/r01_v6_pmc_traffic.json (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs; KiB summed over the kernels of
+# profiles/r01_v7_pmc_traffic.json (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs; KiB summed over the kernels of
 # one step; the read side is not corrected for the gfx950 half-count of wide streaming reads)
 MEASURED_TRAFFIC_DEFAULT_WORKLOAD = None     # filled in below from profiles/ when present
 
 
 def _measured_traffic():
-    path = os.path.join(ROOT, "profiles", "r01_v6_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01_v7_pmc_traffic.json")
     try:
         return json.load(open(path))["bytes_per_step"]
     except Exception:  # noqa: BLE001
@@ -387,7 +387,7 @@ def main():
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": _measured_traffic() if (n == 1_000_000 and L == 256 and world == 1) else None,
                          "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE summed over the step's kernels, "
-                                           "profiles/r01_v6_pmc_traffic.json",
+                                           "profiles/r01_v7_pmc_traffic.json",
                          "algorithmic_bytes_per_launch": algo,
                          "kernel_ms_avg": round(k_ms, 4),
                          "timed_with": "hipEvents on the library's stream around the step's launches"},

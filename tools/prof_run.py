@@ -18,7 +18,8 @@ text, offs, L = corpus.config_corpus(cfg, n_docs=n_docs)
 n = len(offs) - 1
 d_text = ctx.alloc(len(text) + 64); ctx.h2d(d_text, text)
 d_off = ctx.alloc(8 * (n + 1)); ctx.h2d(d_off, offs)
-d_ids = ctx.alloc(4 * n * L); d_mask = ctx.alloc(4 * n * L); d_nreal = ctx.alloc(4 * n)
+moff = int(os.environ.get("MASK_OFF", "0"))          # diagnostic: shift the mask array against the ids array
+d_ids = ctx.alloc(4 * n * L); d_mask = ctx.alloc(4 * n * L + moff) + moff; d_nreal = ctx.alloc(4 * n)
 flags = _native.GZ_PADDING | _native.GZ_TRUNCATION | _native.GZ_TIMING
 if os.environ.get("NO_WORD_TABLE"):
     flags |= _native.GZ_NO_WORD_TABLE
