@@ -515,3 +515,32 @@ def test_random_tables_fuzz(seed, tmp_path):
                 d = int(np.searchsorted(row, bad, side="right") - 1)
                 raise AssertionError((seed, ml, wt, "doc", d, docs[d][:200], got[row[d]:row[d + 1]][:40], ids[row[d]:row[d + 1]][:40]))
             assert np.array_equal(_gather(out["attention_mask"].reshape(-1), ro[:-1], lens), mask[:row[-1]])
+
+
+def test_extreme_batch_shapes(tok, sampler):
+    """Batches far from the benchmark's shape, against the plain-C restatement: a few multi-megabyte documents next to
+    tiny ones (one wave assembles a 600 k-token row), tens of thousands of empty documents, and a batch that is
+    nothing but empty strings."""
+    import gz_oracle_c as OC
+    from corpus import VOCAB_PATH, BPE_PATH
+    co = OC.COracle(open(VOCAB_PATH, "rb").read(), open(BPE_PATH, "rb").read())
+    text, offs, _ = corpus.config_corpus(3, n_docs=30000, seed=51, sampler=sampler)
+    raw = text.tobytes()
+    big1, big2 = raw[:offs[12000]].decode("utf-8"), raw[offs[12000]:offs[21000]].decode("utf-8")
+    docs = ["xin chào", big1, "", "a", big2, "\n\n", "việt nam " * 3] + [""] * 40000 + ["hết"]
+    t, to = OC._pack(docs)
+    t = np.ascontiguousarray(t)
+    for ml, pad, tr in ((None, True, True), (300, True, True)):
+        ids, mask, _, _, row, _, _ = co.call_packed(t, to, max_len=ml, padding=pad, truncation=tr)
+        out = tok.encode_packed(t, to, max_len=ml, padding=pad, truncation=tr)
+        ro = np.asarray(out["row_off"], np.int64)
+        lens = np.diff(row)
+        assert np.array_equal(np.diff(ro), lens)
+        assert np.array_equal(_gather(out["input_ids"].reshape(-1), ro[:-1], lens), ids[:row[-1]])
+        assert np.array_equal(_gather(out["attention_mask"].reshape(-1), ro[:-1], lens), mask[:row[-1]])
+    empties = [""] * 5000
+    out = tok.encode_batch(empties, max_len=8)
+    sp = tok._special_ids()
+    assert np.array_equal(out["input_ids"], np.tile(np.array([sp[1], sp[2]] + [sp[0]] * 6, dtype=np.int32), (5000, 1)))
+    out = tok.encode_batch(empties, empties, max_len=None)
+    assert np.array_equal(np.diff(out["row_off"]), np.full(5000, 4))
