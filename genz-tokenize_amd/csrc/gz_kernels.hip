@@ -322,28 +322,32 @@ __global__ void gz_rowlen_kernel(const int32_t* n_raw, int64_t n_docs, GzShape S
 // single-workgroup exclusive scan of int64 (ragged layouts only; N/1024 trips)
 __global__ __launch_bounds__(1024) void gz_scan_kernel(const int64_t* in, int64_t n, int64_t* out /* n+1 */)
 {
-    __shared__ int64_t wsum[16];
-    __shared__ int64_t carry;
+    // 2 elements per thread and trip, one barrier per trip (double-buffered wave sums, the running carry lives in
+    // every thread)
+    __shared__ int64_t wsum[2][16];
     const int lane = lane_id(), wv = threadIdx.x / WAVE;
-    if (threadIdx.x == 0) carry = 0;
-    __syncthreads();
-    for (int64_t base = 0; base < n; base += 1024) {
-        const int64_t i = base + threadIdx.x;
-        const int64_t v = i < n ? in[i] : 0;
-        int64_t x = v;
+    int64_t carry = 0;
+    int buf = 0;
+    for (int64_t base = 0; base < n; base += 2048, buf ^= 1) {
+        const int64_t i = base + 2 * (int64_t)threadIdx.x;
+        const int64_t a0 = i < n ? in[i] : 0, a1 = i + 1 < n ? in[i + 1] : 0;
+        // in-wave inclusive scan of the 64-bit pair sums
+        int64_t x = a0 + a1;
+        const int64_t mine = x;
 #pragma unroll
         for (int dlt = 1; dlt < WAVE; dlt <<= 1) {
             const int64_t y = __shfl_up(x, dlt, WAVE);
             if (lane >= dlt) x += y;
         }
-        if (lane == WAVE - 1) wsum[wv] = x;
+        if (lane == WAVE - 1) wsum[buf][wv] = x;
         __syncthreads();
-        int64_t pre = carry;
-        for (int k = 0; k < wv; ++k) pre += wsum[k];
-        if (i < n) out[i] = pre + x - v;
-        __syncthreads();
-        if (threadIdx.x == 1023) carry = pre + x;
-        __syncthreads();
+        int64_t pre = carry, all = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { const int64_t w = wsum[buf][k]; if (k < wv) pre += w; all += w; }
+        carry += all;
+        const int64_t e0 = pre + x - mine;
+        if (i < n) out[i] = e0;
+        if (i + 1 < n) out[i + 1] = e0 + a0;
     }
     if (threadIdx.x == 0) out[n] = carry;
 }
