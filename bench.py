@@ -370,7 +370,7 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8 in / int32 out (integer + byte indexing, no floating point)",
+            "dtype": "u8",                                          # bytes in, int32 ids out; integer / byte indexing only
             "data": "synthetic (unigram sampler over the bundled vocab.txt counts, corpus.py; seed %s)" % (
                 "3" if world == 1 else "100+rank"),
             "config": {"workload": "BASELINE configs[2]: %d mixed-length sentences per GPU (70%% 5-30 / 25%% 31-120 / "
