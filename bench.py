@@ -209,16 +209,14 @@ def main():
                 if k > 0:
                     ctx.exchange_select(1)
                     exchange(sets[(k - 1) % nset])
-            else:
-                ctx.sync()
-                if record:
-                    kernel_ms.append(ctx.timing()[0])
         if gather and k_steps > 0:
             ctx.exchange_select(0)
             exchange(sets[(k_steps - 1) % nset])
-        ctx.sync()
-        if gather and record and k_steps > 0:
-            kernel_ms.append(ctx.timing()[0])              # hipEvents of the last step's launches
+        # the steps were enqueued back to back (no host sync in between); this synchronises and reads the hipEvent
+        # pairs recorded around every step's launches on the library's stream
+        hist = ctx.timing_history(64)
+        if record and k_steps > 0:
+            kernel_ms.extend(hist[-k_steps:] if not gather else hist[-1:])
 
     def fence():
         if dist is not None:

@@ -88,6 +88,10 @@ struct gz_ctx {
         int use_words = 0;             // bit 0: whole-word table; bits 8..: timing diagnostics (GZ_ABLATE)
     } pend;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    // timed calls that were chained without a host sync in between: start / end of the main kernels of the last 64
+    static constexpr int RING = 64;
+    hipEvent_t ring[RING][2] = {};
+    uint64_t ring_n = 0;
     double timing[4] = {0, 0, 0, 0};
 
     void* comm = nullptr;
@@ -183,7 +187,7 @@ int enqueue(gz_ctx* c)
     const GzDeviceTables* T = (const GzDeviceTables*)c->t_struct.p;
     if (c->x_used) HIPCHK(c, hipStreamWaitEvent(s, c->ev_x, 0));    // output buffers may still be read by an exchange step
     HIPCHK(c, hipMemsetAsync(c->w_flags.p, 0, 16, s));     // [1] capacity error, [3] a word needs the wide / long kernels
-    if (p.timing) HIPCHK(c, hipEventRecord(c->ev[0], s));
+    if (p.timing) { HIPCHK(c, hipEventRecord(c->ev[0], s)); HIPCHK(c, hipEventRecord(c->ring[c->ring_n % gz_ctx::RING][0], s)); }
     const bool two = p.subs.size() > 1;
     if (two) { HIPCHK(c, hipEventRecord(c->ev_fork, s)); HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0)); }
     for (size_t k = 0; k < p.subs.size(); ++k) {
@@ -194,7 +198,7 @@ int enqueue(gz_ctx* c)
         gz_launch_assemble(T, S, sk);
     }
     if (two) { HIPCHK(c, hipEventRecord(c->ev_join, c->stream2)); HIPCHK(c, hipStreamWaitEvent(s, c->ev_join, 0)); }
-    if (p.timing) HIPCHK(c, hipEventRecord(c->ev[1], s));
+    if (p.timing) { HIPCHK(c, hipEventRecord(c->ev[1], s)); HIPCHK(c, hipEventRecord(c->ring[c->ring_n % gz_ctx::RING][1], s)); c->ring_n++; }
     if (p.ragged) {
         gz_launch_rowscan(p.F, (int64_t*)c->w_rowlen.p, s);
         gz_launch_finalize(c->dev, p.F, s);
@@ -254,7 +258,10 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
     const bool is_pair = pair_off != nullptr;
     if (is_pair && (!token_type_ids || !sequence_id || !pair_len || !status))
         return fail(c, GZ_E_INVALID, "pair mode needs token_type_ids, sequence_id, pair_len and status");
-    if (c->pend.active) { int rc = sync_locked(c); if (rc) return rc; }
+    // A pending call is normally synchronised first.  A DENSE pending call has nothing the host must look at (no
+    // capacity flag), so when this call also comes with host offsets (no size read-back) its kernels are simply
+    // enqueued behind it: the GPU never waits for the host between steps.  gz_sync / gz_timing_history close the chain.
+    if (c->pend.active && (c->pend.ragged || !h_text_off)) { int rc = sync_locked(c); if (rc) return rc; }
 
     const GzShape S = make_shape(max_len, flags);
     const bool dense = is_dense(S);
@@ -502,6 +509,7 @@ int gz_create(int device_id, gz_ctx** out)
     std::memset(c->h_flags, 0, 64);
     if (const char* e = getenv("GZ_WORD_TABLE")) c->no_words_env = (e[0] == '0');
     for (auto& ev : c->ev) hipEventCreate(&ev);
+    for (auto& pr : c->ring) { hipEventCreate(&pr[0]); hipEventCreate(&pr[1]); }
     hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
     hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
@@ -538,6 +546,7 @@ void gz_destroy(gz_ctx* c)
     for (auto& slot : c->tw) for (auto& t : slot)
         for (DBuf* b : {&t.brk, &t.st, &t.en, &t.blkcnt, &t.docw0, &t.wtok, &t.waux, &t.mtok, &t.mlist, &t.blkmiss, &t.blklong, &t.tilecnt, &t.wlist}) release(*b);
     for (auto& ev : c->ev) if (ev) hipEventDestroy(ev);
+    for (auto& pr : c->ring) { if (pr[0]) hipEventDestroy(pr[0]); if (pr[1]) hipEventDestroy(pr[1]); }
     if (c->h_flags) hipHostFree(c->h_flags);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -861,6 +870,25 @@ int gz_memcpy_d2h(gz_ctx* c, void* dst, const void* src, size_t bytes)
     if (!c) return GZ_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     if (bytes) HIPCHK(c, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return GZ_OK;
+}
+
+int gz_timing_history(gz_ctx* c, double* out_ms, int32_t max, int32_t* n_out)
+{
+    if (!c || !out_ms || !n_out || max < 0) return GZ_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->pend.active) { int rc = sync_locked(c); if (rc) return rc; }
+    int n = (int)(c->ring_n < (uint64_t)gz_ctx::RING ? c->ring_n : (uint64_t)gz_ctx::RING);
+    if (n > max) n = max;
+    for (int i = 0; i < n; ++i) {
+        const uint64_t k = c->ring_n - (uint64_t)n + (uint64_t)i;
+        float ms = 0;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->ring[k % gz_ctx::RING][0], c->ring[k % gz_ctx::RING][1]));
+        out_ms[i] = ms;
+    }
+    *n_out = n;
+    c->ring_n = 0;
     return GZ_OK;
 }
 

@@ -25,7 +25,7 @@ SYMBOLS = [
     "gz_version", "gz_create", "gz_destroy", "gz_last_error", "gz_load_tables", "gz_table_info",
     "gz_vocab_entry", "gz_merge_entry", "gz_encode_batch", "gz_encode_batch_device", "gz_encode_batch_device_h", "gz_sync",
     "gz_word_token_counts", "gz_bpe_word", "gz_symbol_utf8", "gz_device_alloc", "gz_device_free", "gz_memcpy_h2d", "gz_memcpy_d2h",
-    "gz_timing", "gz_decoder_snapshot", "gz_decode_batch", "gz_decode_batch_device", "gz_preprocess_batch",
+    "gz_timing", "gz_timing_history", "gz_decoder_snapshot", "gz_decode_batch", "gz_decode_batch_device", "gz_preprocess_batch",
     "gz_preprocess_batch_device", "gz_block_create", "gz_block_release", "gz_block_dlpack", "gz_exchange_select", "gz_comm_unique_id", "gz_comm_init", "gz_gather_rows", "gz_compact_rows", "gz_expand_rows", "gz_compact_rows16", "gz_expand_rows16",
     "gz_host_tables_create", "gz_host_tables_destroy", "gz_host_tables_array", "gz_host_tables_vocab_entry",
     "gz_host_tables_merge_entry", "gz_host_tables_symbol",
@@ -73,6 +73,7 @@ def load_library():
     L.gz_memcpy_h2d.argtypes = [vp, vp, vp, sz]
     L.gz_memcpy_d2h.argtypes = [vp, vp, vp, sz]
     L.gz_timing.argtypes = [vp, P(C.c_double)]
+    L.gz_timing_history.argtypes = [vp, P(C.c_double), i32, P(i32)]
     L.gz_decoder_snapshot.argtypes = [vp]
     L.gz_decode_batch.argtypes = [vp, vp, vp, i64, vp, i32, vp, i64, vp]
     L.gz_decode_batch_device.argtypes = [vp, vp, vp, i64, vp, i32, vp, i64, vp, P(i64)]
@@ -282,6 +283,13 @@ class Context:
 
     def sync(self):
         self._check(self.lib.gz_sync(self.handle))
+
+    def timing_history(self, max_calls: int = 64):
+        """Synchronise; whole-pipeline kernel time (ms) of the last timed calls, oldest first."""
+        buf = (C.c_double * max_calls)()
+        n = C.c_int32()
+        self._check(self.lib.gz_timing_history(self.handle, buf, max_calls, C.byref(n)))
+        return [buf[i] for i in range(n.value)]
 
     def timing(self):
         t = (C.c_double * 4)()

@@ -152,6 +152,10 @@ int  gz_memcpy_d2h(gz_ctx *ctx, void *dst_host, const void *src_device, size_t b
  * out[0] = encode kernel (scan + BPE + lookup + frame/pad/mask), out[1] = ragged finalize, out[2] = pair
  * type-id kernel, out[3] = whole call on the stream.  Unused slots are 0. */
 int  gz_timing(gz_ctx *ctx, double out_ms[4]);
+/* GZ_TIMING calls can be chained without gz_sync in between (a dense call followed by a call that brings host copies
+ * of its offsets is enqueued right behind it).  gz_timing_history synchronises and returns the duration of the main
+ * kernels of the last (up to 64, up to `max`) timed calls, oldest first, then forgets them. */
+int  gz_timing_history(gz_ctx *ctx, double *out_ms, int32_t max, int32_t *n_out);
 
 /* Offline / diagnostic table build on the HOST only (no GPU needed): the same builder gz_load_tables runs, with
  * the integer tables it would upload exposed read-only.  `which`: 0 pair hash (uint64 x2 [slots]: key<<24|rank, merged symbol), 1 merges
