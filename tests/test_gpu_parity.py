@@ -544,3 +544,32 @@ def test_extreme_batch_shapes(tok, sampler):
     assert np.array_equal(out["input_ids"], np.tile(np.array([sp[1], sp[2]] + [sp[0]] * 6, dtype=np.int32), (5000, 1)))
     out = tok.encode_batch(empties, empties, max_len=None)
     assert np.array_equal(np.diff(out["row_off"]), np.full(5000, 4))
+
+
+def test_chained_device_calls(tok, sampler):
+    """Dense calls with host offsets are enqueued behind one another without a host sync (same workspace, stream order):
+    five different batches of growing and shrinking size, chained, must each equal their stand-alone result."""
+    from genz_tokenize import _native
+    ctx = tok._ctx
+    flags = _native.GZ_PADDING | _native.GZ_TRUNCATION | _native.GZ_TIMING
+    jobs = []
+    for seed, n, L in ((1, 3000, 64), (2, 20000, 48), (3, 50, 256), (4, 12000, 128), (5, 1, 16)):
+        text, offs, _ = corpus.config_corpus(3, n_docs=n, seed=200 + seed, sampler=sampler)
+        offs = np.ascontiguousarray(offs, dtype=np.int64)
+        want = tok.encode_packed(text, offs, max_len=L)
+        d_t = ctx.alloc(len(text) + 64); ctx.h2d(d_t, text)
+        d_o = ctx.alloc(8 * (n + 1)); ctx.h2d(d_o, offs)
+        d_i, d_m, d_r = ctx.alloc(4 * n * L), ctx.alloc(4 * n * L), ctx.alloc(4 * n)
+        jobs.append((text, offs, n, L, want, d_t, d_o, d_i, d_m, d_r))
+    ctx.sync()
+    for _, offs, n, L, _, d_t, d_o, d_i, d_m, d_r in jobs:
+        ctx.encode_device(d_t, d_o, 0, 0, n, L, flags, n * L, d_i, d_m, d_n_real=d_r, h_text_off=offs)      # no sync in between
+    hist = ctx.timing_history(64)
+    assert len(hist) == len(jobs) and all(t > 0 for t in hist)
+    for _, offs, n, L, want, d_t, d_o, d_i, d_m, d_r in jobs:
+        ids = np.empty((n, L), np.int32); mask = np.empty((n, L), np.int32); nr = np.empty(n, np.int32)
+        ctx.d2h(ids, d_i); ctx.d2h(mask, d_m); ctx.d2h(nr, d_r)
+        assert np.array_equal(ids, want["input_ids"]) and np.array_equal(mask, want["attention_mask"])
+        assert np.array_equal(nr, want["n_real"])
+        for p in (d_t, d_o, d_i, d_m, d_r):
+            ctx.free(p)
