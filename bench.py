@@ -308,7 +308,7 @@ def main():
                 dts.append(time.perf_counter() - t_a)
             pps[name] = {"ms": round(min(dts) * 1e3, 3), "MB_per_s": round(in_bytes / min(dts) / 1e6, 1), "bytes_out": int(kept)}
         decode_info["preprocess"] = {"workload": "preprocess.py filters over the step's %d documents (%.1f MB), text resident in HBM, "
-                                                 "wall time incl. the per-filter size read-back" % (n, in_bytes / 1e6), **pps}
+                                                 "wall time incl. the size read-back" % (n, in_bytes / 1e6), **pps}
         ctx.free(d_po); ctx.free(d_poo)
     tokens_local = int(n_real.sum())
     tot = np.array([in_bytes, tokens_local, n], dtype=np.float64)

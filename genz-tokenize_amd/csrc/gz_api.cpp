@@ -1026,45 +1026,37 @@ int gz_decode_batch(gz_ctx* c, const int32_t* ids, const int64_t* row_off, int64
 
 // ---- text pre-pass ----------------------------------------------------------------------------------------------------
 namespace {
-// Runs the filters one after the other; the last one writes to out_dev / out_off_dev.  in_bytes = bytes of the input.
+// Runs the filters one after the other.  Every document keeps its slot of the packed input and only shrinks inside
+// it (ping-pong between two slot buffers, one classification pass per filter); the final lengths are scanned and the
+// documents packed into out_dev.  in_bytes = bytes of the input.
 int preprocess_device_locked(gz_ctx* c, const int32_t* ops, int32_t n_ops, const uint8_t* text_dev, const int64_t* off_dev,
                              int64_t n_docs, int64_t in_bytes, uint8_t* out_dev, int64_t capacity, int64_t* out_off_dev, int64_t* total)
 {
     HIPCHK(c, hipSetDevice(c->device));
     int rc;
     for (int k = 0; k < n_ops; ++k) if (ops[k] < GZ_PP_HTML || ops[k] > GZ_PP_URL) return fail(c, GZ_E_INVALID, "unknown filter %d", ops[k]);
-    if ((rc = ensure(c, c->w_pplen, (size_t)(n_docs + 1) * 8))) return rc;
     if ((rc = ensure(c, c->w_ppaux, (size_t)(n_docs + 1) * 8))) return rc;
-    const uint8_t* in = text_dev;
-    const int64_t* in_off = off_dev;
-    *total = in_bytes;
-    for (int k = 0; k < n_ops; ++k) {
-        const bool last = k == n_ops - 1;
-        DBuf& ob = c->w_pp[k & 1];
-        DBuf& oo = c->w_ppoff[k & 1];
-        if (!last) {
-            if ((rc = ensure(c, ob, (size_t)*total + 16))) return rc;      // a filter never grows a document
-            if ((rc = ensure(c, oo, (size_t)(n_docs + 1) * 8))) return rc;
-        }
-        GzPpArgs A{};
-        A.in = in; A.in_off = in_off; A.n_docs = n_docs; A.op = ops[k];
-        A.out_len = (int64_t*)c->w_pplen.p; A.aux = (int64_t*)c->w_ppaux.p;
-        A.out_off_w = last ? out_off_dev : (int64_t*)oo.p;
-        gz_launch_preprocess(A, 0, c->stream);
-        int64_t t = 0;
-        if (n_docs > 0) HIPCHK(c, hipMemcpyAsync(&t, A.out_off_w + n_docs, 8, hipMemcpyDeviceToHost, c->stream));
-        else HIPCHK(c, hipMemsetAsync(A.out_off_w, 0, 8, c->stream));
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        *total = t;
-        if (last && (!out_dev || t > capacity)) {
-            if (!out_dev) return GZ_OK;
-            return fail(c, GZ_E_CAPACITY, "pre-pass output needs %lld bytes, capacity is %lld", (long long)t, (long long)capacity);
-        }
-        A.out = last ? out_dev : (uint8_t*)ob.p;
-        A.out_off = A.out_off_w;
-        gz_launch_preprocess(A, 1, c->stream);
-        in = A.out; in_off = A.out_off;
+    for (int k = 0; k < 2; ++k) {
+        if ((rc = ensure(c, c->w_pp[k], (size_t)in_bytes + 16))) return rc;
+        if ((rc = ensure(c, c->w_ppoff[k], (size_t)(n_docs + 1) * 8))) return rc;          // lengths after filter k, k+2, ...
     }
+    const uint8_t* in = text_dev;
+    const int64_t* in_len = nullptr;
+    for (int k = 0; k < n_ops; ++k) {
+        GzPpArgs A{};
+        A.in = in; A.in_off = off_dev; A.in_len = in_len; A.n_docs = n_docs; A.op = ops[k];
+        A.out = (uint8_t*)c->w_pp[k & 1].p; A.out_len = (int64_t*)c->w_ppoff[k & 1].p; A.aux = (int64_t*)c->w_ppaux.p;
+        if (ops[k] == GZ_PP_HTML) gz_launch_preprocess(A, 0, c->stream);                  // does the last '<' close?
+        gz_launch_preprocess(A, 1, c->stream);
+        in = A.out; in_len = A.out_len;
+    }
+    gz_launch_scan64(in_len, n_docs, out_off_dev, c->stream);
+    *total = 0;
+    if (n_docs > 0) HIPCHK(c, hipMemcpyAsync(total, out_off_dev + n_docs, 8, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (!out_dev) return GZ_OK;
+    if (*total > capacity) return fail(c, GZ_E_CAPACITY, "pre-pass output needs %lld bytes, capacity is %lld", (long long)*total, (long long)capacity);
+    gz_launch_pp_pack(in, off_dev, in_len, n_docs, out_dev, out_off_dev, c->stream);
     HIPCHK(c, hipStreamSynchronize(c->stream));
     HIPCHK(c, hipGetLastError());
     return GZ_OK;

@@ -81,14 +81,17 @@ void gz_launch_bpe_word(const GzDeviceTables* T_dev, const uint8_t* word, int64_
 void gz_launch_decode(const GzDecTable& D, const int32_t* ids, const int64_t* row_off, int64_t n_rows, int64_t* row_bytes,
                       int64_t* out_off, uint8_t* out, int64_t capacity, hipStream_t s);
 
-// text pre-pass (gz_preproc.inc): one filter over packed documents
+// text pre-pass (gz_preproc.inc): one filter over documents that sit in the slots of a packed text
 struct GzPpArgs {
-    const uint8_t* in; const int64_t* in_off;   // document d = in[in_off[d] - in_off[0] .. in_off[d+1] - in_off[0])
+    const uint8_t* in; const int64_t* in_off;   // slot of document d = in[in_off[d] - in_off[0] ...
+    const int64_t* in_len;                      // ... its current length (nullptr: the whole slot, in_off[d+1] - in_off[d])
     int64_t n_docs;
-    uint8_t* out; const int64_t* out_off;       // pass 1: where document d goes
-    int64_t* out_len;                           // pass 0: bytes document d keeps ...
-    int64_t* out_off_w;                         // ... and their exclusive scan [n_docs + 1]
-    int64_t* aux;                               // [n_docs] filter state handed from pass 0 to pass 1 (html: unclosed '<')
+    uint8_t* out;                               // pass 1: same slots, another buffer
+    int64_t* out_len;                           // pass 1: the new lengths
+    int64_t* aux;                               // [n_docs] html: position of the unclosed '<' (pass 0 -> pass 1)
     int32_t op;                                 // GZ_PP_*
 };
 void gz_launch_preprocess(const GzPpArgs& A, int pass, hipStream_t s);
+void gz_launch_scan64(const int64_t* len, int64_t n, int64_t* out_off /* n+1 */, hipStream_t s);
+void gz_launch_pp_pack(const uint8_t* in, const int64_t* in_off, const int64_t* len, int64_t n_docs, uint8_t* out, const int64_t* out_off,
+                       hipStream_t s);

@@ -531,7 +531,7 @@ void gz_launch_decode(const GzDecTable& D, const int32_t* ids, const int64_t* ro
     }
 }
 
-// one filter, one pass (0: out_len + aux, then the caller scans; 1: write)
+// one filter, one pass (0: html look-ahead only; 1: classify + write into the document's slot + new length)
 void gz_launch_preprocess(const GzPpArgs& A, int pass, hipStream_t s)
 {
     if (A.n_docs <= 0) return;
@@ -544,5 +544,15 @@ void gz_launch_preprocess(const GzPpArgs& A, int pass, hipStream_t s)
     case PP_URL:     hipLaunchKernelGGL(gz_pp_kernel<PP_URL>, grid, block, 0, s, A, pass); break;
     default: break;
     }
-    if (pass == 0) hipLaunchKernelGGL(gz_scan_kernel, dim3(1), dim3(1024), 0, s, (const int64_t*)A.out_len, A.n_docs, A.out_off_w);
+}
+
+void gz_launch_scan64(const int64_t* len, int64_t n, int64_t* out_off /* n+1 */, hipStream_t s)
+{
+    hipLaunchKernelGGL(gz_scan_kernel, dim3(1), dim3(1024), 0, s, len, n, out_off);
+}
+
+void gz_launch_pp_pack(const uint8_t* in, const int64_t* in_off, const int64_t* len, int64_t n_docs, uint8_t* out, const int64_t* out_off, hipStream_t s)
+{
+    if (n_docs > 0)
+        hipLaunchKernelGGL(gz_pp_pack_kernel, dim3((unsigned)((n_docs + 3) / 4)), dim3(WAVE * 4), 0, s, in, in_off, len, n_docs, out, out_off);
 }
