@@ -582,6 +582,8 @@ int gz_load_tables(gz_ctx* c, const uint8_t* vocab, size_t vocab_len, const uint
     HIPCHK(c, hipStreamSynchronize(c->stream));
     GzDeviceTables& D = c->dev;
     D.pair_tab = (const GzPairSlot*)c->t_pair.p;   D.pair_mask = (uint32_t)H.pair_tab.size() - 1;
+    D.pair_shift = 32; while ((size_t(1) << (32 - D.pair_shift)) < H.pair_tab.size()) --D.pair_shift;
+    D.pair_pad = 0;
     D.merges = (const GzMergeInfo*)c->t_merges.p; D.n_ranks = (uint32_t)H.merges.size();
     D.sym_ids = (const GzSymIds*)c->t_symids.p;  D.n_symbols = (uint32_t)H.symbols.size();
     D.bmp = (const GzCpSyms*)c->t_bmp.p;

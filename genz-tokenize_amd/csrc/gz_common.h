@@ -24,26 +24,19 @@ constexpr uint32_t GZ_SYM_UNKNOWN = 0x80000000u;
 constexpr uint32_t GZ_SYM_LASTBIT = 0x40000000u;
 constexpr uint32_t GZ_NO_SYMBOL   = 0xFFFFFFFFu;      // table entry: code point has no interned symbol
 constexpr uint32_t GZ_RANK_NONE   = 0xFFFFFFFFu;      // "pair is not in bpe_ranks" (the float('inf') of tokenize.py:71)
-constexpr uint64_t GZ_PAIR_EMPTY  = ~0ull;
+constexpr uint32_t GZ_PAIR_EMPTY  = 0xFFFFFFFFu;      // `left` of an empty pair slot
 
 // pair -> rank hash table entry:  [ left:20 | right:20 | rank:24 ]
-GZ_HD uint64_t gz_pair_key(uint32_t a, uint32_t b) { return ((uint64_t)a << 20) | b; }
-GZ_HD uint64_t gz_pair_entry(uint32_t a, uint32_t b, uint32_t rank) { return (gz_pair_key(a, b) << 24) | rank; }
-GZ_HD uint32_t gz_pair_hash(uint32_t a, uint32_t b)
-{
-    uint32_t h = a * 0x9E3779B1u + b * 0x85EBCA6Bu;
-    h ^= h >> 15;
-    h *= 0x2C1B3C6Du;
-    h ^= h >> 13;
-    return h;
-}
+// slot of the pair (a, b) in a table of 2^(32 - shift) slots: multiplicative hashing, the TOP bits of one multiply-add
+// (three VALU instructions in the merge loop, which runs one probe per iteration)
+GZ_HD uint32_t gz_pair_slot(uint32_t a, uint32_t b, uint32_t shift) { return (a * 0x9E3779B1u + b * 0x85EBCA6Bu) >> shift; }
 GZ_HD uint32_t gz_cp_hash(uint32_t cp)
 {
     uint32_t h = cp * 0x9E3779B1u;
     return h ^ (h >> 16);
 }
 
-struct GzPairSlot  { uint64_t keyrank; uint32_t merged; uint32_t pad; };   // keyrank == GZ_PAIR_EMPTY -> empty
+struct GzPairSlot  { uint32_t left, right, merged, rank; };              // left == GZ_PAIR_EMPTY -> empty; 32-bit compares only
 struct GzMergeInfo { uint32_t left, right, merged, pad; };   // indexed by rank
 struct GzSymIds    { int32_t nonfinal, final_; };            // vocab id of  sym+"@@"  /  sym minus "</w>"
 struct GzCpSyms    { uint32_t plain, final_; };              // symbol of  c  /  c+"</w>"   (GZ_NO_SYMBOL if none)
@@ -76,7 +69,8 @@ GZ_HD uint32_t gz_word_hash2(const uint64_t k[4], uint32_t len)
 
 // Device-resident tables, passed to kernels by value.
 struct GzDeviceTables {
-    const GzPairSlot*  pair_tab;    uint32_t pair_mask;      // slots-1 (power of two)
+    const GzPairSlot*  pair_tab;    uint32_t pair_mask;      // slots-1 (power of two; >= 16 slots)
+    uint32_t           pair_shift;  uint32_t pair_pad;       // 32 - log2(slots): gz_pair_slot(a, b, pair_shift)
     const GzMergeInfo* merges;      uint32_t n_ranks;
     const GzSymIds*    sym_ids;     uint32_t n_symbols;
     const GzCpSyms*    bmp;                                   // 65536 entries

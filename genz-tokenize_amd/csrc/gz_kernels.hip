@@ -73,12 +73,11 @@ __device__ __forceinline__ int wave_sum(int v)
 __device__ __forceinline__ uint32_t probe_rank(const GzDeviceTables& T, uint32_t a, uint32_t b)
 {
     if ((a | b) & 0xFFF00000u) return GZ_RANK_NONE;          // a code point outside every table never merges
-    uint32_t h = gz_pair_hash(a, b) & T.pair_mask;
-    const uint64_t key = gz_pair_key(a, b);
+    uint32_t h = gz_pair_slot(a, b, T.pair_shift);
     for (;;) {
-        uint64_t e = T.pair_tab[h].keyrank;
-        if ((e >> 24) == key) return (uint32_t)e & 0xFFFFFFu;
-        if (e == GZ_PAIR_EMPTY) return GZ_RANK_NONE;
+        const uint4 v = *reinterpret_cast<const uint4*>(&T.pair_tab[h]);
+        if (v.x == a && v.y == b) return v.w;
+        if (v.x == GZ_PAIR_EMPTY) return GZ_RANK_NONE;
         h = (h + 1) & T.pair_mask;
     }
 }
@@ -87,13 +86,11 @@ __device__ __forceinline__ uint32_t probe_rank(const GzDeviceTables& T, uint32_t
 __device__ __forceinline__ uint32_t probe_pair(const GzDeviceTables& T, uint32_t a, uint32_t b, uint32_t& merged)
 {
     if ((a | b) & 0xFFF00000u) return GZ_RANK_NONE;
-    uint32_t h = gz_pair_hash(a, b) & T.pair_mask;
-    const uint64_t key = gz_pair_key(a, b);
+    uint32_t h = gz_pair_slot(a, b, T.pair_shift);
     for (;;) {
         const uint4 v = *reinterpret_cast<const uint4*>(&T.pair_tab[h]);
-        const uint64_t e = ((uint64_t)v.y << 32) | v.x;
-        if ((e >> 24) == key) { merged = v.z; return v.x & 0xFFFFFFu; }
-        if (e == GZ_PAIR_EMPTY) return GZ_RANK_NONE;
+        if (v.x == a && v.y == b) { merged = v.z; return v.w; }
+        if (v.x == GZ_PAIR_EMPTY) return GZ_RANK_NONE;
         h = (h + 1) & T.pair_mask;
     }
 }

@@ -302,13 +302,15 @@ int gz_build_tables(const uint8_t* vocab, size_t vocab_len, const uint8_t* bpe, 
     {
         size_t slots = 16;
         while (slots < 2 * pairs.size()) slots <<= 1;
-        T.pair_tab.assign(slots, GzPairSlot{GZ_PAIR_EMPTY, 0, 0});
+        uint32_t shift = 32;
+        while ((size_t(1) << (32 - shift)) < slots) --shift;
+        T.pair_tab.assign(slots, GzPairSlot{GZ_PAIR_EMPTY, 0, 0, 0});
         uint32_t worst = 0;
         for (const Pair& p : pairs) {
-            size_t h = gz_pair_hash(p.a, p.b) & (slots - 1);
+            size_t h = gz_pair_slot(p.a, p.b, shift);
             uint32_t probes = 1;
-            while (T.pair_tab[h].keyrank != GZ_PAIR_EMPTY) { h = (h + 1) & (slots - 1); ++probes; }
-            T.pair_tab[h] = GzPairSlot{gz_pair_entry(p.a, p.b, p.rank), T.merges[p.rank].merged, 0};
+            while (T.pair_tab[h].left != GZ_PAIR_EMPTY) { h = (h + 1) & (slots - 1); ++probes; }
+            T.pair_tab[h] = GzPairSlot{p.a, p.b, T.merges[p.rank].merged, p.rank};
             worst = std::max(worst, probes);
         }
         T.max_probe = worst;

@@ -11,12 +11,8 @@ NONE = -1
 M32 = 0xFFFFFFFF
 
 
-def pair_hash(a, b):
-    h = (a * 0x9E3779B1 + b * 0x85EBCA6B) & M32
-    h ^= h >> 15
-    h = (h * 0x2C1B3C6D) & M32
-    h ^= h >> 13
-    return h
+def pair_slot(a, b, shift):
+    return ((a * 0x9E3779B1 + b * 0x85EBCA6B) & M32) >> shift
 
 
 def cp_hash(cp):
@@ -26,10 +22,10 @@ def cp_hash(cp):
 
 class TableSim:
     def __init__(self, H):
-        pt = H.array(0)
-        self.pair = [int(x) for x in pt[:, 0]]
-        self.pair_merged = [int(x) & 0xFFFFFFFF for x in pt[:, 1]]
+        pt = H.array(0)                                   # {left, right, merged, rank}
+        self.pair = [tuple(int(x) for x in row) for row in pt]
         self.mask = len(self.pair) - 1
+        self.shift = 32 - (len(self.pair).bit_length() - 1)
         self.merges = H.array(1)
         self.sym_ids = H.array(2)
         self.bmp = H.array(3)
@@ -39,14 +35,13 @@ class TableSim:
     def probe(self, a, b):
         if (a | b) & 0xFFF00000:
             return None
-        h = pair_hash(a, b) & self.mask
-        key = (a << 20) | b
+        h = pair_slot(a, b, self.shift)
         while True:
-            e = self.pair[h]
-            if (e >> 24) == key:
-                assert self.pair_merged[h] == int(self.merges[e & 0xFFFFFF][2])
-                return e & 0xFFFFFF
-            if e == 0xFFFFFFFFFFFFFFFF:
+            left, right, merged, rank = self.pair[h]
+            if left == a and right == b:
+                assert merged == int(self.merges[rank][2])
+                return rank
+            if left == M32:
                 return None
             h = (h + 1) & self.mask
 
