@@ -156,6 +156,28 @@ def add_noise(text: np.ndarray, offsets: np.ndarray, seed: int, rate: float = 0.
     return np.frombuffer(b"".join(docs), dtype=np.uint8).copy(), np.array(offs, dtype=np.int64)
 
 
+def add_typos(text: np.ndarray, offsets: np.ndarray, seed: int, rate: float) -> np.ndarray:
+    """Out-of-vocabulary sensitivity (bench.py): ~rate of the words (separated by single spaces / document
+    boundaries, as Sampler.docs writes them) have every byte replaced by a random lowercase ASCII letter or digit, so
+    they miss every whole-word table and run the merge loop to many pieces.  Vectorised; offsets are unchanged and the
+    result is valid UTF-8.  Returns the new text."""
+    rng = np.random.Generator(np.random.PCG64(seed))
+    text = np.ascontiguousarray(text, dtype=np.uint8)
+    is_sp = text == 0x20
+    step = is_sp.astype(np.int64)
+    inner = np.asarray(offsets[1:-1], dtype=np.int64)
+    inner = inner[inner < len(text)]
+    np.add.at(step, inner, 1)                              # a document boundary also ends a word
+    wid = np.cumsum(step)
+    n_words = int(wid[-1]) + 1 if len(wid) else 0
+    pick = rng.random(n_words) < rate
+    sel = pick[wid] & ~is_sp
+    out = text.copy()
+    alpha = np.frombuffer(b"abcdefghijklmnopqrstuvwxyz0123456789", dtype=np.uint8)
+    out[sel] = alpha[rng.integers(0, len(alpha), size=int(sel.sum()))]
+    return out
+
+
 def config_corpus(cfg: int, n_docs: Optional[int] = None, seed: Optional[int] = None,
                   sampler: Optional[Sampler] = None):
     """(text, offsets, max_len) for BASELINE.json configs 2, 3, 4 (per shard) and 5."""

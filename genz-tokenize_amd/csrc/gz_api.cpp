@@ -88,8 +88,9 @@ struct gz_ctx {
         int use_words = 0;             // bit 0: whole-word table; bits 8..: timing diagnostics (GZ_ABLATE)
     } pend;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    // timed calls that were chained without a host sync in between: start / end of the main kernels of the last 64
-    static constexpr int RING = 64;
+    // timed calls that were chained without a host sync in between: start / end of the main kernels of the last RING
+    // (events are created on first use: an untimed context never pays for them)
+    static constexpr int RING = 1024;
     hipEvent_t ring[RING][2] = {};
     uint64_t ring_n = 0;
     double timing[4] = {0, 0, 0, 0};
@@ -98,7 +99,7 @@ struct gz_ctx {
     int rank = 0, world = 1;
 
     DBuf t_words2, t_words0;
-    struct TextWs { DBuf brk, st, en, blkcnt, docw0, wtok, waux, mtok, mlist, blkmiss, blklong, tilecnt, wlist; } tw[2][2];   // [slot][text]
+    struct TextWs { DBuf brk, st, en, blkcnt, docw0, wtok, waux, mtok, mlist, blkmiss, blklong, tilecnt, wlist, grpblk; } tw[2][2];   // [slot][text]
     hipStream_t stream2 = nullptr;       // sub-batches alternate between the two streams
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // exchange step (compact / gather / expand) on its own stream, so that it overlaps the next call's kernels
@@ -187,7 +188,11 @@ int enqueue(gz_ctx* c)
     const GzDeviceTables* T = (const GzDeviceTables*)c->t_struct.p;
     if (c->x_used) HIPCHK(c, hipStreamWaitEvent(s, c->ev_x, 0));    // output buffers may still be read by an exchange step
     HIPCHK(c, hipMemsetAsync(c->w_flags.p, 0, 16, s));     // [1] capacity error, [3] a word needs the wide / long kernels
-    if (p.timing) { HIPCHK(c, hipEventRecord(c->ev[0], s)); HIPCHK(c, hipEventRecord(c->ring[c->ring_n % gz_ctx::RING][0], s)); }
+    if (p.timing) {
+        hipEvent_t* slot = c->ring[c->ring_n % gz_ctx::RING];
+        if (!slot[0]) { HIPCHK(c, hipEventCreate(&slot[0])); HIPCHK(c, hipEventCreate(&slot[1])); }
+        HIPCHK(c, hipEventRecord(c->ev[0], s)); HIPCHK(c, hipEventRecord(slot[0], s));
+    }
     const bool two = p.subs.size() > 1;
     if (two) { HIPCHK(c, hipEventRecord(c->ev_fork, s)); HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0)); }
     for (size_t k = 0; k < p.subs.size(); ++k) {
@@ -361,14 +366,15 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
             if ((rc2 = ensure(c, W.brk, bm)) || (rc2 = ensure(c, W.st, bm)) || (rc2 = ensure(c, W.en, bm)) ||
                 (rc2 = ensure(c, W.blkcnt, (size_t)(X.nblk + 2) * 4)) || (rc2 = ensure(c, W.docw0, (size_t)(S2.n_docs + 2) * 4)) ||
                 (rc2 = ensure(c, W.wtok, (size_t)wmax * 4)) || (rc2 = ensure(c, W.waux, (size_t)wmax * 4)) ||
-                (rc2 = ensure(c, W.mtok, (size_t)(Bt + 32) * 4)) || (rc2 = ensure(c, W.mlist, (size_t)wmax * 4)) ||
+                (rc2 = ensure(c, W.mtok, (size_t)(Bt + 32) * 4)) || (rc2 = ensure(c, W.mlist, (size_t)wmax * 16)) ||
+                (rc2 = ensure(c, W.grpblk, (size_t)(wmax / 64 + 4) * 4)) ||
                 (rc2 = ensure(c, W.blkmiss, (size_t)(X.nblk + 2) * 4)) || (rc2 = ensure(c, W.blklong, (size_t)(X.nblk + 2) * 4)) ||
                 (rc2 = ensure(c, W.tilecnt, (size_t)(X.nblk + 2) * 8)) || (rc2 = ensure(c, W.wlist, (size_t)(wmax + 2) * 4)))
                 return rc2;
             X.brk = (uint16_t*)W.brk.p; X.st = (uint16_t*)W.st.p; X.en = (uint16_t*)W.en.p;
             X.blkcnt = (uint32_t*)W.blkcnt.p; X.docw0 = (uint32_t*)W.docw0.p;
             X.wtok = (uint32_t*)W.wtok.p; X.waux = (uint32_t*)W.waux.p; X.mtok = (int32_t*)W.mtok.p;
-            X.mlist = (uint32_t*)W.mlist.p; X.blkmiss = (uint32_t*)W.blkmiss.p; X.blklong = (uint32_t*)W.blklong.p; X.tilecnt = (uint16_t*)W.tilecnt.p; X.wlist = (uint32_t*)W.wlist.p;
+            X.mlist = (uint4*)W.mlist.p; X.grpblk = (uint32_t*)W.grpblk.p; X.wmax = wmax; X.blkmiss = (uint32_t*)W.blkmiss.p; X.blklong = (uint32_t*)W.blklong.p; X.tilecnt = (uint16_t*)W.tilecnt.p; X.wlist = (uint32_t*)W.wlist.p;
         }
     }
     if (!dense) {
@@ -457,6 +463,7 @@ static int build_word_table(gz_ctx* c)
             tab0[h] = e;
         }
         if ((rc = upload(c, c->t_words0, tab0))) return rc;
+        HIPCHK(c, hipStreamSynchronize(c->stream));          // (tab0 dies at the end of this block)
         c->dev.words0 = (const GzWordSlot0*)c->t_words0.p;
         c->dev.word0_mask = (uint32_t)slots0 - 1;
     }
@@ -470,6 +477,7 @@ static int build_word_table(gz_ctx* c)
             tab2[h] = e;
         }
         if ((rc = upload(c, c->t_words2, tab2))) return rc;
+        HIPCHK(c, hipStreamSynchronize(c->stream));          // (tab2 dies at the end of this block)
         c->dev.words2 = (const GzWordSlot2*)c->t_words2.p;
         c->dev.word2_mask = (uint32_t)slots2 - 1;
     }
@@ -509,7 +517,6 @@ int gz_create(int device_id, gz_ctx** out)
     std::memset(c->h_flags, 0, 64);
     if (const char* e = getenv("GZ_WORD_TABLE")) c->no_words_env = (e[0] == '0');
     for (auto& ev : c->ev) hipEventCreate(&ev);
-    for (auto& pr : c->ring) { hipEventCreate(&pr[0]); hipEventCreate(&pr[1]); }
     hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
     hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
@@ -544,7 +551,7 @@ void gz_destroy(gz_ctx* c)
                     &c->w_nreal, &c->w_status, &c->w_raw, &c->w_arena, &c->w_flags, &c->w_word, &c->w_wordout})
         release(*b);
     for (auto& slot : c->tw) for (auto& t : slot)
-        for (DBuf* b : {&t.brk, &t.st, &t.en, &t.blkcnt, &t.docw0, &t.wtok, &t.waux, &t.mtok, &t.mlist, &t.blkmiss, &t.blklong, &t.tilecnt, &t.wlist}) release(*b);
+        for (DBuf* b : {&t.brk, &t.st, &t.en, &t.blkcnt, &t.docw0, &t.wtok, &t.waux, &t.mtok, &t.mlist, &t.blkmiss, &t.blklong, &t.tilecnt, &t.wlist, &t.grpblk}) release(*b);
     for (auto& ev : c->ev) if (ev) hipEventDestroy(ev);
     for (auto& pr : c->ring) { if (pr[0]) hipEventDestroy(pr[0]); if (pr[1]) hipEventDestroy(pr[1]); }
     if (c->h_flags) hipHostFree(c->h_flags);
@@ -1186,12 +1193,12 @@ int compact_impl(gz_ctx* c, const int32_t* rows_dev, const int32_t* n_real_dev, 
     if ((rc = x_begin(c))) return rc;
     gz_launch_row_offsets(n_real_dev, n_rows, off, c->xstream);
     gz_launch_compact(rows_dev, off, n_rows, row_len, out_dev, bits, c->xstream);
-    uint32_t total = 0;
-    HIPCHK(c, hipMemcpyAsync(&total, off + n_rows, 4, hipMemcpyDeviceToHost, c->xstream));
+    uint32_t* total = reinterpret_cast<uint32_t*>(c->h_pick) + 60;           // pinned (h_pick is 256 bytes; its tail is free)
+    HIPCHK(c, hipMemcpyAsync(total, off + n_rows, 4, hipMemcpyDeviceToHost, c->xstream));
     if ((rc = x_end(c))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->xstream));
     HIPCHK(c, hipGetLastError());
-    *total_host = total;
+    *total_host = *total;
     return GZ_OK;
 }
 int expand_impl(gz_ctx* c, const void* compact_dev, int bits, const int32_t* n_real_dev, int64_t n_rows, int32_t row_len,
@@ -1344,32 +1351,50 @@ int gz_gather_rows(gz_ctx* c, const int32_t* send_dev, int64_t n_rows_local, int
     if (!c->comm) return fail(c, GZ_E_RCCL, "gz_comm_init has not been called");
     if (root < 0 || root >= c->world || row_len <= 0 || n_rows_local < 0 || !rows_per_rank)
         return fail(c, GZ_E_INVALID, "bad arguments");
+    // Everything that can be refused is refused BEFORE the group is opened: a rank that leaves between ncclGroupStart and
+    // ncclGroupEnd, or whose count differs from what the root expects, hangs every other rank.
+    if (rows_per_rank[c->rank] != n_rows_local)
+        return fail(c, GZ_E_INVALID, "rows_per_rank[%d] = %lld but n_rows_local = %lld", c->rank,
+                    (long long)rows_per_rank[c->rank], (long long)n_rows_local);
+    int64_t total_rows = 0;
+    for (int q = 0; q < c->world; ++q) {
+        if (rows_per_rank[q] < 0) return fail(c, GZ_E_INVALID, "rows_per_rank[%d] is negative", q);
+        total_rows += rows_per_rank[q];
+    }
+    if (n_rows_local > 0 && !send_dev) return fail(c, GZ_E_INVALID, "send_dev is NULL");
+    if (c->rank == root && total_rows > 0 && !recv_dev) return fail(c, GZ_E_INVALID, "recv_dev is NULL on the root");
     HIPCHK(c, hipSetDevice(c->device));
     const int ncclInt32 = 2;
     { int rc0 = x_begin(c); if (rc0) return rc0; }
-    // direct gatherv: the root posts one receive per peer, each peer one send, all inside one group, so every
-    // peer's block travels over its own xGMI link concurrently (no ring)
-    int r = g_rccl.GroupStart();
-    if (r == 0 && c->rank == root) {
+    // the root's own block is a device-to-device copy (outside the group: it is not an RCCL operation)
+    if (c->rank == root && n_rows_local > 0) {
         int64_t row0 = 0;
-        for (int q = 0; q < c->world && r == 0; ++q) {
-            const size_t cnt = (size_t)rows_per_rank[q] * (size_t)row_len;
-            int32_t* dst = recv_dev + row0 * (int64_t)row_len;
-            if (q == root) {
-                if (cnt && dst != send_dev)
-                    HIPCHK(c, hipMemcpyAsync(dst, send_dev, cnt * 4, hipMemcpyDeviceToDevice, c->xstream));
-            } else if (cnt) {
-                r = g_rccl.Recv(dst, cnt, ncclInt32, q, c->comm, c->xstream);
-            }
-            row0 += rows_per_rank[q];
-        }
-    } else if (r == 0) {
-        const size_t cnt = (size_t)n_rows_local * (size_t)row_len;
-        if (cnt) r = g_rccl.Send(send_dev, cnt, ncclInt32, root, c->comm, c->xstream);
+        for (int q = 0; q < root; ++q) row0 += rows_per_rank[q];
+        int32_t* dst = recv_dev + row0 * (int64_t)row_len;
+        if (dst != send_dev)
+            HIPCHK(c, hipMemcpyAsync(dst, send_dev, (size_t)n_rows_local * (size_t)row_len * 4, hipMemcpyDeviceToDevice, c->xstream));
     }
-    int r2 = g_rccl.GroupEnd();
-    if (r != 0 || r2 != 0)
-        return fail(c, GZ_E_RCCL, "RCCL gather failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r ? r : r2) : "error");
+    // direct gatherv: the root posts one receive per peer, each peer one send, all inside one group, so every
+    // peer's block travels over its own xGMI link concurrently (no ring).  The group is always closed.
+    int r = g_rccl.GroupStart();
+    if (r == 0) {
+        if (c->rank == root) {
+            int64_t row0 = 0;
+            for (int q = 0; q < c->world; ++q) {
+                const size_t cnt = (size_t)rows_per_rank[q] * (size_t)row_len;
+                if (q != root && cnt && r == 0)
+                    r = g_rccl.Recv(recv_dev + row0 * (int64_t)row_len, cnt, ncclInt32, q, c->comm, c->xstream);
+                row0 += rows_per_rank[q];
+            }
+        } else {
+            const size_t cnt = (size_t)n_rows_local * (size_t)row_len;
+            if (cnt) r = g_rccl.Send(send_dev, cnt, ncclInt32, root, c->comm, c->xstream);
+        }
+        const int r2 = g_rccl.GroupEnd();
+        if (r == 0) r = r2;
+    }
+    if (r != 0)
+        return fail(c, GZ_E_RCCL, "RCCL gather failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error");
     { int rc1 = x_end(c); if (rc1) return rc1; }
     return GZ_OK;
 }

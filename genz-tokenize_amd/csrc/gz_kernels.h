@@ -46,8 +46,10 @@ struct GzTextBufs {              // one text (A or B) of a batch and its per-cal
     uint32_t* docw0;             // [n_docs+1] index of each document's first word
     uint32_t* wtok;              // [words] id, or MISS | token count
     uint32_t* waux;              // [words] misses: byte offset of the word (its ids are at mtok[offset ...])
-    uint32_t* mlist;             // [words] the misses of block b, compact, at mlist[blkcnt[b] ...]
-    uint32_t* blkmiss;           // [nblk] number of misses per block
+    uint4* mlist;                // [words] the misses of block b, compact, at mlist[blkcnt[b] ...]: {word index, byte offset, pending record, 0}
+    uint32_t* blkmiss;           // [nblk+1] number of misses per block; scanned in place before gz_miss_kernel ([nblk] = total)
+    uint32_t* grpblk;            // [words/64 + 2] block that holds miss number 64 g (written by the scan)
+    int64_t wmax;                // upper bound of the number of words (sizes of the per-word arrays)
     uint32_t* blklong;           // [nblk] block holds a word for gz_long_kernel (zeroed per call)
     uint32_t* wlist;             // [0] count, then the words (indices) that need 32 or 64 lanes (zeroed count per call)
     uint16_t* tilecnt;           // [4 * nblk] word starts of the block that lie before each of its four 1-KiB tiles

@@ -4,8 +4,11 @@ import collections, csv, glob, sys
 f = (glob.glob(sys.argv[1] + '/*/*kernel_trace.csv') + glob.glob(sys.argv[1] + '/*kernel_trace.csv'))[0]
 by = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
-    if r['Kernel_Name'].startswith('gz_'):
-        by[r['Kernel_Name'].split('(')[0]].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+    name = r['Kernel_Name']
+    if name.startswith('void '):                      # template instances: "void gz_rows1_kernel<512>(...)"
+        name = name[5:]
+    if name.startswith('gz_'):
+        by[name.split('(')[0]].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
 tot = 0
 for k, v in by.items():
     last = v[-3:]
