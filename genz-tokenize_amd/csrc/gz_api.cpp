@@ -15,7 +15,7 @@
 
 namespace {
 
-thread_local std::string g_create_err;
+#define g_create_err gz_create_err()     // shared with gz_host_api.cpp (error text of calls that have no context)
 
 struct DBuf {                       // grow-only device buffer
     void* p = nullptr;
@@ -121,6 +121,12 @@ struct gz_ctx {
     DBuf t_dec_entries, t_dec_bytes, w_dec_ids, w_dec_roff, w_dec_rb, w_dec_ooff, w_dec_out;
     DBuf w_pp[2], w_ppoff[2], w_pplen, w_ppaux, w_pp_in, w_pp_inoff;      // text pre-pass
     DBuf w_tiny[8][2];                                                     // texts of fewer than 16 bytes, see encode_device_locked
+    // host path with copies overlapped (gz_encode_batch_csr): copy-in / copy-out streams, per-sub-batch events and buffers
+    hipStream_t s_in = nullptr, s_out = nullptr;
+    static constexpr int CSR_SUBS = 16;
+    hipEvent_t ev_in[CSR_SUBS] = {}, ev_done[CSR_SUBS] = {};
+    DBuf w_csr_ids[2], w_csr_mask[2], w_csr_comp, w_csr_nreal, w_csr_off32;
+    uint32_t* h_tot = nullptr;           // pinned: compact size of every sub-batch
     bool building_words = false;         // the whole-word table is being built: ignore diagnostics
     bool no_words_env = false;           // GZ_WORD_TABLE=0 in the environment
 };
@@ -250,6 +256,60 @@ int sync_locked(gz_ctx* c)
     return GZ_OK;
 }
 
+// One text (A or B) of a (sub-)batch: its per-call workspace in slot W, sized from the byte and document counts.
+// tb = first byte of the batch on the device, off = its [n_docs + 1] absolute offsets (device), Bt = its bytes.
+int setup_text(gz_ctx* c, gz_ctx::TextWs& W, DBuf& tiny, const uint8_t* tb, const int64_t* off, int64_t Bt, int64_t n_docs,
+               hipStream_t s, GzTextBufs& X)
+{
+    if (Bt < 0) return fail(c, GZ_E_INVALID, "offsets are not non-decreasing");
+    if (Bt >= (int64_t)0xFFFF0000ll) return fail(c, GZ_E_LIMIT, "a batch of 4 GiB or more of text must be split");
+    X.tb = tb;
+    if (Bt > 0 && Bt < 16) {
+        // the kernels read the 16 bytes that END at the last byte of the text (load16 / load4_tail move a load
+        // back instead of running past B): give a tiny text 16 bytes of lead-in and zeroed slack behind it
+        // (one buffer per sub-batch: they are filled before any kernel runs)
+        int rc3;
+        if ((rc3 = ensure(c, tiny, 64))) return rc3;
+        HIPCHK(c, hipMemsetAsync(tiny.p, 0, 64, s));
+        HIPCHK(c, hipMemcpyAsync((uint8_t*)tiny.p + 16, X.tb, (size_t)Bt, hipMemcpyDeviceToDevice, s));
+        X.tb = (const uint8_t*)tiny.p + 16;
+    }
+    X.off = off;
+    X.B = Bt;
+    X.nblk = Bt / 4096 + 1;
+    const size_t bm = (size_t)((Bt + 1024) / 1024) * 128 + 64 + 4096;
+    int64_t wmax = Bt / 2 + n_docs + 2; if (wmax > Bt + 2) wmax = Bt + 2;
+    int rc2;
+    if ((rc2 = ensure(c, W.brk, bm)) || (rc2 = ensure(c, W.st, bm)) || (rc2 = ensure(c, W.en, bm)) ||
+        (rc2 = ensure(c, W.blkcnt, (size_t)(X.nblk + 2) * 4)) || (rc2 = ensure(c, W.docw0, (size_t)(n_docs + 2) * 4)) ||
+        (rc2 = ensure(c, W.wtok, (size_t)wmax * 4)) || (rc2 = ensure(c, W.waux, (size_t)wmax * 4)) ||
+        (rc2 = ensure(c, W.mtok, (size_t)(Bt + 32) * 4)) || (rc2 = ensure(c, W.mlist, (size_t)wmax * 16)) ||
+        (rc2 = ensure(c, W.grpblk, (size_t)(wmax / 64 + 4) * 4)) ||
+        (rc2 = ensure(c, W.blkmiss, (size_t)(X.nblk + 2) * 4)) || (rc2 = ensure(c, W.blklong, (size_t)(X.nblk + 2) * 4)) ||
+        (rc2 = ensure(c, W.tilecnt, (size_t)(X.nblk + 2) * 8)) || (rc2 = ensure(c, W.wlist, (size_t)(wmax + 2) * 4)))
+        return rc2;
+    X.brk = (uint16_t*)W.brk.p; X.st = (uint16_t*)W.st.p; X.en = (uint16_t*)W.en.p;
+    X.blkcnt = (uint32_t*)W.blkcnt.p; X.docw0 = (uint32_t*)W.docw0.p;
+    X.wtok = (uint32_t*)W.wtok.p; X.waux = (uint32_t*)W.waux.p; X.mtok = (int32_t*)W.mtok.p;
+    X.mlist = (uint4*)W.mlist.p; X.grpblk = (uint32_t*)W.grpblk.p; X.wmax = wmax; X.blkmiss = (uint32_t*)W.blkmiss.p;
+    X.blklong = (uint32_t*)W.blklong.p; X.tilecnt = (uint16_t*)W.tilecnt.p; X.wlist = (uint32_t*)W.wlist.p;
+    return GZ_OK;
+}
+
+bool ids_fit_16(gz_ctx* c)
+{
+    for (int32_t id : c->host.enc_ids) if (id < 0 || id > 0xFFFF) return false;
+    return true;
+}
+
+int use_words_flags(gz_ctx* c, uint32_t flags)
+{
+    const char* ab = getenv("GZ_ABLATE");       // timing diagnostics only: results are wrong when set
+    const int ablate = (ab && !c->building_words) ? atoi(ab) : 0;
+    const int use_words = (c->dev.words0 != nullptr && !(flags & GZ_NO_WORD_TABLE) && !c->no_words_env) ? 1 : 0;
+    return use_words | (ablate << 8);
+}
+
 int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off, const uint8_t* pair,
                          const int64_t* pair_off, int64_t n_docs, int32_t max_len, uint32_t flags, int64_t capacity,
                          int32_t* input_ids, int32_t* attention_mask, int32_t* token_type_ids, int32_t* sequence_id,
@@ -313,10 +373,7 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
         if (dpw > GZ_MAX_DOCS_PER_WAVE) dpw = GZ_MAX_DOCS_PER_WAVE;
         if (const char* e = getenv("GZ_DOCS_PER_WAVE")) { int v = atoi(e); if (v >= 1 && v <= GZ_MAX_DOCS_PER_WAVE) dpw = v; }
         docs_per_wave = (int)dpw;
-        const char* ab = getenv("GZ_ABLATE");       // timing diagnostics only: results are wrong when set
-        const int ablate = (ab && !c->building_words) ? atoi(ab) : 0;
-        const int use_words = (c->dev.words0 != nullptr && !(flags & GZ_NO_WORD_TABLE) && !c->no_words_env) ? 1 : 0;
-        p.use_words = use_words | (ablate << 8);
+        p.use_words = use_words_flags(c, flags);
     }
     int32_t* raw = nullptr;
     int32_t* n_raw = n_real;
@@ -340,41 +397,10 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
         S2.raw = raw; S2.n_real = n_raw + lo;
         S2.docs_per_wave = docs_per_wave;
         for (int tx = 0; tx < S2.n_texts; ++tx) {
-            GzTextBufs& X = S2.X[tx];
-            gz_ctx::TextWs& W = c->tw[k & 1][tx];
             const int64_t* cut = tx ? cutB : cutA;
-            const int64_t Bt = cut[k + 1] - cut[k];
-            if (Bt < 0) return fail(c, GZ_E_INVALID, "offsets are not non-decreasing");
-            if (Bt >= (int64_t)0xFFFF0000ll) return fail(c, GZ_E_LIMIT, "a batch of 4 GiB or more of text must be split");
-            X.tb = (tx ? pair : text) + cut[k];
-            if (Bt > 0 && Bt < 16) {
-                // the kernels read the 16 bytes that END at the last byte of the text (load16 / load4_tail move a load
-                // back instead of running past B): give a tiny text 16 bytes of lead-in and zeroed slack behind it
-                DBuf& tiny = c->w_tiny[k & 7][tx];                          // (one per sub-batch: they are filled before any kernel runs)
-                int rc3;
-                if ((rc3 = ensure(c, tiny, 64))) return rc3;
-                HIPCHK(c, hipMemsetAsync(tiny.p, 0, 64, c->stream));
-                HIPCHK(c, hipMemcpyAsync((uint8_t*)tiny.p + 16, X.tb, (size_t)Bt, hipMemcpyDeviceToDevice, c->stream));
-                X.tb = (const uint8_t*)tiny.p + 16;
-            }
-            X.off = (tx ? pair_off : text_off) + lo;
-            X.B = Bt;
-            X.nblk = Bt / 4096 + 1;
-            const size_t bm = (size_t)((Bt + 1024) / 1024) * 128 + 64 + 4096;
-            int64_t wmax = Bt / 2 + S2.n_docs + 2; if (wmax > Bt + 2) wmax = Bt + 2;
-            int rc2;
-            if ((rc2 = ensure(c, W.brk, bm)) || (rc2 = ensure(c, W.st, bm)) || (rc2 = ensure(c, W.en, bm)) ||
-                (rc2 = ensure(c, W.blkcnt, (size_t)(X.nblk + 2) * 4)) || (rc2 = ensure(c, W.docw0, (size_t)(S2.n_docs + 2) * 4)) ||
-                (rc2 = ensure(c, W.wtok, (size_t)wmax * 4)) || (rc2 = ensure(c, W.waux, (size_t)wmax * 4)) ||
-                (rc2 = ensure(c, W.mtok, (size_t)(Bt + 32) * 4)) || (rc2 = ensure(c, W.mlist, (size_t)wmax * 16)) ||
-                (rc2 = ensure(c, W.grpblk, (size_t)(wmax / 64 + 4) * 4)) ||
-                (rc2 = ensure(c, W.blkmiss, (size_t)(X.nblk + 2) * 4)) || (rc2 = ensure(c, W.blklong, (size_t)(X.nblk + 2) * 4)) ||
-                (rc2 = ensure(c, W.tilecnt, (size_t)(X.nblk + 2) * 8)) || (rc2 = ensure(c, W.wlist, (size_t)(wmax + 2) * 4)))
-                return rc2;
-            X.brk = (uint16_t*)W.brk.p; X.st = (uint16_t*)W.st.p; X.en = (uint16_t*)W.en.p;
-            X.blkcnt = (uint32_t*)W.blkcnt.p; X.docw0 = (uint32_t*)W.docw0.p;
-            X.wtok = (uint32_t*)W.wtok.p; X.waux = (uint32_t*)W.waux.p; X.mtok = (int32_t*)W.mtok.p;
-            X.mlist = (uint4*)W.mlist.p; X.grpblk = (uint32_t*)W.grpblk.p; X.wmax = wmax; X.blkmiss = (uint32_t*)W.blkmiss.p; X.blklong = (uint32_t*)W.blklong.p; X.tilecnt = (uint16_t*)W.tilecnt.p; X.wlist = (uint32_t*)W.wlist.p;
+            int rc2 = setup_text(c, c->tw[k & 1][tx], c->w_tiny[k & 7][tx], (tx ? pair : text) + cut[k], (tx ? pair_off : text_off) + lo,
+                                 cut[k + 1] - cut[k], S2.n_docs, c->stream, S2.X[tx]);
+            if (rc2) return rc2;
         }
     }
     if (!dense) {
@@ -540,6 +566,12 @@ void gz_destroy(gz_ctx* c)
     for (auto& e : c->ev_tok) if (e) hipEventDestroy(e);
     if (c->ev_x) hipEventDestroy(c->ev_x);
     if (c->xstream) hipStreamDestroy(c->xstream);
+    if (c->s_in) hipStreamDestroy(c->s_in);
+    if (c->s_out) hipStreamDestroy(c->s_out);
+    for (auto& e : c->ev_in) if (e) hipEventDestroy(e);
+    for (auto& e : c->ev_done) if (e) hipEventDestroy(e);
+    if (c->h_tot) hipHostFree(c->h_tot);
+    for (DBuf* b : {&c->w_csr_ids[0], &c->w_csr_ids[1], &c->w_csr_mask[0], &c->w_csr_mask[1], &c->w_csr_comp, &c->w_csr_nreal, &c->w_csr_off32}) release(*b);
     if (c->h_pick) hipHostFree(c->h_pick);
     release(c->w_pick); release(c->w_rowoff32);
     for (auto& t2 : c->w_tiny) for (auto& t : t2) release(t);
@@ -787,6 +819,136 @@ int gz_encode_batch(gz_ctx* c, const uint8_t* text, const int64_t* text_off, con
                               attention_mask, token_type_ids, sequence_id, row_off, pair_len, n_real, status);
 }
 
+int gz_host_alloc(gz_ctx* c, size_t bytes, void** ptr)
+{
+    if (!c || !ptr) return GZ_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    hipError_t e = hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault);
+    if (e != hipSuccess) { *ptr = nullptr; return fail(c, GZ_E_NOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
+    return GZ_OK;
+}
+
+int gz_host_free(gz_ctx* c, void* ptr)
+{
+    if (!c) return GZ_E_INVALID;
+    HIPCHK(c, hipSetDevice(c->device));
+    if (ptr) HIPCHK(c, hipHostFree(ptr));
+    return GZ_OK;
+}
+
+// Host buffers in, CSR out, copies overlapped with the kernels.  The batch is cut into sub-batches of documents:
+//   copy-in stream : text of sub-batch k+1 travels while
+//   main stream    : the pipeline of sub-batch k runs (dense rows into one of two device slots), then the rows lose
+//                    their padding (scan of n_real + gz_compact_kernel) into the sub-batch's region of a device buffer,
+//   copy-out stream: the real entries of sub-batch k-1 travel back, straight to their final place in the caller's array.
+// What crosses PCIe is the text, 8 bytes per document of offsets, and 2 (or 4) bytes per real token + 4 per document.
+int gz_encode_batch_csr(gz_ctx* c, const uint8_t* text, const int64_t* text_off, int64_t n_docs, int32_t max_len, uint32_t flags,
+                        void* tokens, int64_t capacity, int32_t bits, int32_t* n_real, int64_t* total_out)
+{
+    if (!c) return GZ_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->have_tables) return fail(c, GZ_E_NOTABLES, "gz_load_tables has not been called");
+    if (n_docs < 0 || !text_off || !n_real || !total_out || capacity < 0 || (capacity > 0 && !tokens) || (bits != 16 && bits != 32))
+        return fail(c, GZ_E_INVALID, "bad arguments");
+    const GzShape S = make_shape(max_len, flags);
+    if (!is_dense(S)) return fail(c, GZ_E_INVALID, "gz_encode_batch_csr needs max_len >= 1 with padding and truncation (rows are cut to max_len)");
+    if (bits == 16 && !ids_fit_16(c)) return fail(c, GZ_E_LIMIT, "the vocabulary has ids that do not fit 16 bits");
+    for (int64_t i = 0; i < n_docs; ++i)
+        if (text_off[i + 1] < text_off[i]) return fail(c, GZ_E_INVALID, "text_off is not non-decreasing at %lld", (long long)i);
+    *total_out = 0;
+    if (n_docs == 0) return GZ_OK;
+    const int64_t tb = text_off[n_docs] - text_off[0];
+    if (tb > 0 && !text) return fail(c, GZ_E_INVALID, "text is NULL");
+    if (c->pend.active) { int rc0 = sync_locked(c); if (rc0) return rc0; }
+    if (c->x_used) HIPCHK(c, hipStreamSynchronize(c->xstream));
+    if (!c->s_in) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking));
+        for (auto& e : c->ev_in) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto& e : c->ev_done) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIPCHK(c, hipHostMalloc((void**)&c->h_tot, sizeof(uint32_t) * gz_ctx::CSR_SUBS, hipHostMallocDefault));
+    }
+    // sub-batches of about 32 MB of text (equal document counts), at most CSR_SUBS
+    int nsub = (int)((tb + (32ll << 20) - 1) / (32ll << 20));
+    if (nsub < 1) nsub = 1;
+    if (nsub > gz_ctx::CSR_SUBS) nsub = gz_ctx::CSR_SUBS;
+    if ((int64_t)nsub > n_docs) nsub = (int)n_docs;
+    const size_t esz = bits == 16 ? 2 : 4;
+    int64_t nmax = 0;
+    for (int k = 0; k < nsub; ++k) { const int64_t lo = (int64_t)k * n_docs / nsub, hi = (int64_t)(k + 1) * n_docs / nsub; if (hi - lo > nmax) nmax = hi - lo; }
+    // a document of b bytes has at most min(max_len, b + 2) entries: regions of the device compact buffer start at these bounds
+    std::vector<int64_t> bound((size_t)nsub + 1, 0);
+    for (int k = 0; k < nsub; ++k) {
+        const int64_t lo = (int64_t)k * n_docs / nsub, hi = (int64_t)(k + 1) * n_docs / nsub;
+        const int64_t by_bytes = (text_off[hi] - text_off[lo]) + 2 * (hi - lo), by_rows = (hi - lo) * (int64_t)max_len;
+        int64_t b = by_bytes < by_rows ? by_bytes : by_rows;
+        b = (b + 7) & ~(int64_t)7;                                          // regions stay 16-byte aligned for either entry size
+        bound[(size_t)k + 1] = bound[(size_t)k] + b;
+    }
+    int rc;
+    if ((rc = ensure(c, c->w_text, (size_t)tb + 16)) || (rc = ensure(c, c->w_toff, (size_t)(n_docs + 1) * 8)) ||
+        (rc = ensure(c, c->w_csr_nreal, (size_t)(n_docs + 1) * 4)) || (rc = ensure(c, c->w_csr_off32, (size_t)(nmax + 2) * 4)) ||
+        (rc = ensure(c, c->w_csr_comp, (size_t)bound[(size_t)nsub] * esz + 64)))
+        return rc;
+    for (int q = 0; q < (nsub > 1 ? 2 : 1); ++q)
+        if ((rc = ensure(c, c->w_csr_ids[q], (size_t)nmax * (size_t)max_len * 4 + 64)) || (rc = ensure(c, c->w_csr_mask[q], (size_t)nmax * (size_t)max_len * 4 + 64)))
+            return rc;
+    const GzDeviceTables* T = (const GzDeviceTables*)c->t_struct.p;
+    const uint8_t* d_text = (const uint8_t*)c->w_text.p - text_off[0];
+    const int64_t* d_off = (const int64_t*)c->w_toff.p;
+    const int use_words = use_words_flags(c, flags);
+    hipStream_t s = c->stream;
+    // ---- everything the GPU has to do is enqueued first ...
+    HIPCHK(c, hipMemcpyAsync(c->w_toff.p, text_off, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice, c->s_in));
+    for (int k = 0; k < nsub; ++k) {
+        const int64_t lo = (int64_t)k * n_docs / nsub, hi = (int64_t)(k + 1) * n_docs / nsub;
+        const int64_t b0 = text_off[lo], b1 = text_off[hi];
+        if (b1 > b0) HIPCHK(c, hipMemcpyAsync((uint8_t*)c->w_text.p + (b0 - text_off[0]), text + b0, (size_t)(b1 - b0), hipMemcpyHostToDevice, c->s_in));
+        HIPCHK(c, hipEventRecord(c->ev_in[k], c->s_in));
+    }
+    HIPCHK(c, hipMemsetAsync(c->w_flags.p, 0, 16, s));
+    for (int k = 0; k < nsub; ++k) {
+        const int64_t lo = (int64_t)k * n_docs / nsub, hi = (int64_t)(k + 1) * n_docs / nsub;
+        GzAsmArgs A{};
+        A.n_texts = 1; A.n_docs = hi - lo; A.dense = 1; A.max_len = max_len;
+        A.ids = (int32_t*)c->w_csr_ids[k & 1].p; A.mask = (int32_t*)c->w_csr_mask[k & 1].p;
+        A.raw = nullptr; A.n_real = (int32_t*)c->w_csr_nreal.p + lo;
+        A.docs_per_wave = GZ_MAX_DOCS_PER_WAVE;
+        HIPCHK(c, hipStreamWaitEvent(s, c->ev_in[k], 0));
+        if ((rc = setup_text(c, c->tw[k & 1][0], c->w_tiny[k & 7][0], d_text + text_off[lo], d_off + lo, text_off[hi] - text_off[lo], A.n_docs, s, A.X[0])))
+            return rc;
+        gz_launch_pipeline_text(T, A.X[0], A.n_docs, use_words, (int32_t*)c->w_flags.p + 3, s);
+        gz_launch_assemble(T, A, s);
+        uint32_t* off32 = (uint32_t*)c->w_csr_off32.p;
+        gz_launch_row_offsets(A.n_real, A.n_docs, off32, s);
+        gz_launch_compact(A.ids, off32, A.n_docs, max_len, (uint8_t*)c->w_csr_comp.p + (size_t)bound[(size_t)k] * esz, bits, s);
+        HIPCHK(c, hipMemcpyAsync(&c->h_tot[k], off32 + A.n_docs, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipEventRecord(c->ev_done[k], s));
+    }
+    HIPCHK(c, hipGetLastError());
+    // ... then the host follows the sub-batches: as soon as one is compact, its entries go to their final place
+    int64_t total = 0;
+    int ret = GZ_OK;
+    for (int k = 0; k < nsub; ++k) {
+        const int64_t lo = (int64_t)k * n_docs / nsub, hi = (int64_t)(k + 1) * n_docs / nsub;
+        HIPCHK(c, hipEventSynchronize(c->ev_done[k]));
+        const int64_t tk = c->h_tot[k];
+        if (ret == GZ_OK && total + tk <= capacity) {
+            HIPCHK(c, hipStreamWaitEvent(c->s_out, c->ev_done[k], 0));
+            if (tk) HIPCHK(c, hipMemcpyAsync((uint8_t*)tokens + (size_t)total * esz, (uint8_t*)c->w_csr_comp.p + (size_t)bound[(size_t)k] * esz,
+                                             (size_t)tk * esz, hipMemcpyDeviceToHost, c->s_out));
+            HIPCHK(c, hipMemcpyAsync(n_real + lo, (int32_t*)c->w_csr_nreal.p + lo, (size_t)(hi - lo) * 4, hipMemcpyDeviceToHost, c->s_out));
+        } else ret = GZ_E_CAPACITY;
+        total += tk;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->s_out));
+    HIPCHK(c, hipStreamSynchronize(s));
+    *total_out = total;
+    if (ret) return fail(c, ret, "the batch has %lld real entries, capacity is %lld", (long long)total, (long long)capacity);
+    return GZ_OK;
+}
+
 int gz_word_token_counts(gz_ctx* c, int which_text, int32_t* counts, int64_t capacity, int64_t* doc_first, int64_t* n_words)
 {
     if (!c || !counts || !doc_first || !n_words || which_text < 0 || which_text > 1) return c ? fail(c, GZ_E_INVALID, "bad arguments") : GZ_E_INVALID;
@@ -1018,14 +1180,14 @@ int gz_decode_batch(gz_ctx* c, const int32_t* ids, const int64_t* row_off, int64
     if (n_ids) HIPCHK(c, hipMemcpyAsync(c->w_dec_ids.p, ids + row_off[0], (size_t)n_ids * 4, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->w_dec_roff.p, row_off, (size_t)(n_rows + 1) * 8, hipMemcpyHostToDevice, c->stream));
     int64_t total = 0;
-    if ((rc = decode_device_locked(c, (const int32_t*)c->w_dec_ids.p, (const int64_t*)c->w_dec_roff.p, n_rows, unk, unk_len, nullptr, 0,
+    if ((rc = decode_device_locked(c, (const int32_t*)c->w_dec_ids.p - row_off[0], (const int64_t*)c->w_dec_roff.p, n_rows, unk, unk_len, nullptr, 0,
                                    (int64_t*)c->w_dec_ooff.p, &total))) return rc;
     HIPCHK(c, hipMemcpy(out_off, c->w_dec_ooff.p, (size_t)(n_rows + 1) * 8, hipMemcpyDeviceToHost));
     if (total > capacity) return fail(c, GZ_E_CAPACITY, "decode needs %lld bytes, capacity is %lld", (long long)total, (long long)capacity);
     if (total == 0) return GZ_OK;
     if ((rc = ensure(c, c->w_dec_out, (size_t)total))) return rc;
     GzDecTable D{(const GzDecEntry*)c->t_dec_entries.p, (const uint8_t*)c->t_dec_bytes.p, c->dec_n_ids};
-    gz_launch_decode(D, (const int32_t*)c->w_dec_ids.p, (const int64_t*)c->w_dec_roff.p, n_rows, nullptr, (int64_t*)c->w_dec_ooff.p,
+    gz_launch_decode(D, (const int32_t*)c->w_dec_ids.p - row_off[0], (const int64_t*)c->w_dec_roff.p, n_rows, nullptr, (int64_t*)c->w_dec_ooff.p,
                      (uint8_t*)c->w_dec_out.p, total, c->stream);
     HIPCHK(c, hipMemcpyAsync(out, c->w_dec_out.p, (size_t)total, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
@@ -1054,6 +1216,7 @@ int preprocess_device_locked(gz_ctx* c, const int32_t* ops, int32_t n_ops, const
     for (int k = 0; k < n_ops; ++k) {
         GzPpArgs A{};
         A.in = in; A.in_off = off_dev; A.in_len = in_len; A.n_docs = n_docs; A.op = ops[k];
+        A.in_abs = k == 0 ? 1 : 0;                                                         // the caller's text; later filters read their own slot buffers
         A.out = (uint8_t*)c->w_pp[k & 1].p; A.out_len = (int64_t*)c->w_ppoff[k & 1].p; A.aux = (int64_t*)c->w_ppaux.p;
         if (ops[k] == GZ_PP_HTML) gz_launch_preprocess(A, 0, c->stream);                  // does the last '<' close?
         gz_launch_preprocess(A, 1, c->stream);
@@ -1102,7 +1265,7 @@ int gz_preprocess_batch(gz_ctx* c, const int32_t* ops, int32_t n_ops, const uint
     if (nbytes) HIPCHK(c, hipMemcpyAsync(c->w_pp_in.p, text + text_off[0], (size_t)nbytes, hipMemcpyHostToDevice, c->stream));
     HIPCHK(c, hipMemcpyAsync(c->w_pp_inoff.p, text_off, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice, c->stream));
     int64_t total = 0;
-    if ((rc = preprocess_device_locked(c, ops, n_ops, (const uint8_t*)c->w_pp_in.p, (const int64_t*)c->w_pp_inoff.p, n_docs, nbytes,
+    if ((rc = preprocess_device_locked(c, ops, n_ops, (const uint8_t*)c->w_pp_in.p - text_off[0], (const int64_t*)c->w_pp_inoff.p, n_docs, nbytes,
                                        (uint8_t*)fin.p, nbytes, (int64_t*)fino.p, &total))) return rc;
     HIPCHK(c, hipMemcpy(out_off, fino.p, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost));
     if (total > capacity) return fail(c, GZ_E_CAPACITY, "pre-pass output needs %lld bytes, capacity is %lld", (long long)total, (long long)capacity);
@@ -1172,13 +1335,22 @@ void* gz_block_dlpack(gz_block* b, int32_t ndim, const int64_t* shape, int32_t d
     return mt;
 }
 
+// PyCapsule destructor for a capsule made from gz_block_dlpack's result: a capsule that was never consumed (its name is
+// still "dltensor"; a consumer renames it to "used_dltensor" and takes over the deleter) releases its reference to
+// the block.  Plain C, resolved against the running interpreter: this library does not link libpython.
+void gz_dlpack_capsule_destructor(void* capsule)
+{
+    typedef int (*isvalid_t)(void*, const char*);
+    typedef void* (*getptr_t)(void*, const char*);
+    static const isvalid_t isvalid = (isvalid_t)dlsym(RTLD_DEFAULT, "PyCapsule_IsValid");
+    static const getptr_t getptr = (getptr_t)dlsym(RTLD_DEFAULT, "PyCapsule_GetPointer");
+    if (!capsule || !isvalid || !getptr || !isvalid(capsule, "dltensor")) return;
+    DlManagedTensor* mt = (DlManagedTensor*)getptr(capsule, "dltensor");
+    if (mt && mt->deleter) mt->deleter(mt);
+}
+
 // ---- compact rows for the exchange step -----------------------------------------------------------------------------
 namespace {
-bool ids_fit_16(gz_ctx* c)
-{
-    for (int32_t id : c->host.enc_ids) if (id < 0 || id > 0xFFFF) return false;
-    return true;
-}
 int compact_impl(gz_ctx* c, const int32_t* rows_dev, const int32_t* n_real_dev, int64_t n_rows, int32_t row_len, void* out_dev,
                  int bits, int64_t* total_host)
 {
@@ -1240,75 +1412,6 @@ int gz_expand_rows16(gz_ctx* c, const uint16_t* compact_dev, const int32_t* n_re
                      int32_t* ids_dev, int32_t* mask_dev)
 {
     return expand_impl(c, compact_dev, 16, n_real_dev, n_rows, row_len, ids_dev, mask_dev);
-}
-
-// ---- host-only table build (diagnostics, offline checks; no GPU) ------------------------------------------------------
-struct gz_host_tables { GzHostTables T; };
-
-int gz_host_tables_create(const uint8_t* vocab, size_t vocab_len, const uint8_t* bpe, size_t bpe_len,
-                          const char* const specials[5], gz_host_tables** out)
-{
-    if (!out || !specials) return GZ_E_INVALID;
-    *out = nullptr;
-    gz_host_tables* h = new (std::nothrow) gz_host_tables();
-    if (!h) return GZ_E_NOMEM;
-    static const uint8_t empty = 0;
-    int rc;
-    try {
-        std::string err;
-        rc = gz_build_tables(vocab ? vocab : &empty, vocab_len, bpe ? bpe : &empty, bpe_len, specials, h->T, err);
-        if (rc) g_create_err = err;
-    } catch (...) {
-        rc = GZ_E_NOMEM;
-    }
-    if (rc) { delete h; return rc; }
-    *out = h;
-    return GZ_OK;
-}
-
-void gz_host_tables_destroy(gz_host_tables* t) { delete t; }
-
-int gz_host_tables_array(gz_host_tables* t, int which, const void** data, int64_t* count)
-{
-    if (!t || !data || !count) return GZ_E_INVALID;
-    GzHostTables& H = t->T;
-    switch (which) {
-        case 0: *data = H.pair_tab.data(); *count = (int64_t)H.pair_tab.size(); break;
-        case 1: *data = H.merges.data();   *count = (int64_t)H.merges.size(); break;
-        case 2: *data = H.sym_ids.data();  *count = (int64_t)H.sym_ids.size(); break;
-        case 3: *data = H.bmp.data();      *count = (int64_t)H.bmp.size(); break;
-        case 4: *data = H.astral.data();   *count = (int64_t)H.astral.size(); break;
-        case 5: *data = H.special_ids;     *count = 5; break;
-        default: return GZ_E_INVALID;
-    }
-    return GZ_OK;
-}
-
-int gz_host_tables_vocab_entry(gz_host_tables* t, int64_t i, const uint8_t** utf8, int32_t* len, int32_t* id)
-{
-    if (!t || i < 0 || i >= (int64_t)t->T.enc_words.size()) return GZ_E_INVALID;
-    if (utf8) *utf8 = (const uint8_t*)t->T.enc_words[i].data();
-    if (len) *len = (int32_t)t->T.enc_words[i].size();
-    if (id) *id = t->T.enc_ids[i];
-    return GZ_OK;
-}
-
-int gz_host_tables_merge_entry(gz_host_tables* t, int64_t i, const uint8_t** utf8, int32_t* len, int32_t* n_fields, int32_t* rank)
-{
-    if (!t || i < 0 || i >= (int64_t)t->T.rank_keys.size()) return GZ_E_INVALID;
-    if (utf8) *utf8 = (const uint8_t*)t->T.rank_keys[i].data();
-    if (len) *len = (int32_t)t->T.rank_keys[i].size();
-    if (n_fields) *n_fields = t->T.rank_nfields[i];
-    if (rank) *rank = t->T.rank_vals[i];
-    return GZ_OK;
-}
-
-int gz_host_tables_symbol(gz_host_tables* t, int32_t symbol, const uint8_t** utf8, int32_t* len)
-{
-    if (!t || symbol < 0 || symbol >= (int32_t)t->T.symbols.size()) return GZ_E_INVALID;
-    if (utf8) *utf8 = (const uint8_t*)t->T.symbols[symbol].data();
-    if (len) *len = (int32_t)t->T.symbols[symbol].size();
-    return GZ_OK;
 }
 
 // ---- multi-GPU exchange step --------------------------------------------------------------------------------------

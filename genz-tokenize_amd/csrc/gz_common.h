@@ -26,7 +26,7 @@ constexpr uint32_t GZ_NO_SYMBOL   = 0xFFFFFFFFu;      // table entry: code point
 constexpr uint32_t GZ_RANK_NONE   = 0xFFFFFFFFu;      // "pair is not in bpe_ranks" (the float('inf') of tokenize.py:71)
 constexpr uint32_t GZ_PAIR_EMPTY  = 0xFFFFFFFFu;      // `left` of an empty pair slot
 
-// pair -> rank hash table entry:  [ left:20 | right:20 | rank:24 ]
+// pair -> rank hash table entry: GzPairSlot {left, right, merged, rank} below (16 bytes, 32-bit compares only)
 // slot of the pair (a, b) in a table of 2^(32 - shift) slots: multiplicative hashing, the TOP bits of one multiply-add
 // (three VALU instructions in the merge loop, which runs one probe per iteration)
 GZ_HD uint32_t gz_pair_slot(uint32_t a, uint32_t b, uint32_t shift) { return (a * 0x9E3779B1u + b * 0x85EBCA6Bu) >> shift; }
@@ -116,6 +116,9 @@ struct GzHostTables {
 // Returns GZ_OK / GZ_E_UTF8 / GZ_E_LIMIT; `err` receives a message.
 int gz_build_tables(const uint8_t* vocab, size_t vocab_len, const uint8_t* bpe, size_t bpe_len,
                     const char* const specials[5], GzHostTables& out, std::string& err);
+
+// error text of C-ABI calls that have no context (gz_create, gz_host_tables_create, ...); thread-local (gz_host_api.cpp)
+std::string& gz_create_err();
 
 // true when the n bytes are valid UTF-8 holding no whitespace code point (so the regex "\S+" sees ONE word)
 bool gz_is_plain_word(const uint8_t* p, size_t n);

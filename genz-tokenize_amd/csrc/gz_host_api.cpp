@@ -1,0 +1,94 @@
+// Host-only part of the C ABI (include/genz_tokenize.h): the loader + table builder exposed without a GPU
+// (gz_host_tables_*).  No HIP in this file: it is also built with g++ -fsanitize=address,undefined together with
+// gz_tables.cpp (make asan -> libgenz_tokenize_host_asan.so) so that the CPU test-suite can run the parser of
+// untrusted file bytes (loader rules L1-L8) under the sanitizers.
+#include "../../include/genz_tokenize.h"
+#include "gz_common.h"
+
+#include <new>
+#include <string>
+
+std::string& gz_create_err()
+{
+    static thread_local std::string err;
+    return err;
+}
+
+extern "C" {
+
+#ifdef GZ_HOST_ONLY
+// the sanitizer build has no contexts: only the two context-free entry points of the main library
+int gz_version(void) { return GZ_VERSION; }
+const char* gz_last_error(gz_ctx*) { return gz_create_err().c_str(); }
+#endif
+
+// ---- host-only table build (diagnostics, offline checks; no GPU) ------------------------------------------------------
+struct gz_host_tables { GzHostTables T; };
+
+int gz_host_tables_create(const uint8_t* vocab, size_t vocab_len, const uint8_t* bpe, size_t bpe_len,
+                          const char* const specials[5], gz_host_tables** out)
+{
+    if (!out || !specials) return GZ_E_INVALID;
+    *out = nullptr;
+    gz_host_tables* h = new (std::nothrow) gz_host_tables();
+    if (!h) return GZ_E_NOMEM;
+    static const uint8_t empty = 0;
+    int rc;
+    try {
+        std::string err;
+        rc = gz_build_tables(vocab ? vocab : &empty, vocab_len, bpe ? bpe : &empty, bpe_len, specials, h->T, err);
+        if (rc) gz_create_err() = err;
+    } catch (...) {
+        rc = GZ_E_NOMEM;
+    }
+    if (rc) { delete h; return rc; }
+    *out = h;
+    return GZ_OK;
+}
+
+void gz_host_tables_destroy(gz_host_tables* t) { delete t; }
+
+int gz_host_tables_array(gz_host_tables* t, int which, const void** data, int64_t* count)
+{
+    if (!t || !data || !count) return GZ_E_INVALID;
+    GzHostTables& H = t->T;
+    switch (which) {
+        case 0: *data = H.pair_tab.data(); *count = (int64_t)H.pair_tab.size(); break;
+        case 1: *data = H.merges.data();   *count = (int64_t)H.merges.size(); break;
+        case 2: *data = H.sym_ids.data();  *count = (int64_t)H.sym_ids.size(); break;
+        case 3: *data = H.bmp.data();      *count = (int64_t)H.bmp.size(); break;
+        case 4: *data = H.astral.data();   *count = (int64_t)H.astral.size(); break;
+        case 5: *data = H.special_ids;     *count = 5; break;
+        default: return GZ_E_INVALID;
+    }
+    return GZ_OK;
+}
+
+int gz_host_tables_vocab_entry(gz_host_tables* t, int64_t i, const uint8_t** utf8, int32_t* len, int32_t* id)
+{
+    if (!t || i < 0 || i >= (int64_t)t->T.enc_words.size()) return GZ_E_INVALID;
+    if (utf8) *utf8 = (const uint8_t*)t->T.enc_words[i].data();
+    if (len) *len = (int32_t)t->T.enc_words[i].size();
+    if (id) *id = t->T.enc_ids[i];
+    return GZ_OK;
+}
+
+int gz_host_tables_merge_entry(gz_host_tables* t, int64_t i, const uint8_t** utf8, int32_t* len, int32_t* n_fields, int32_t* rank)
+{
+    if (!t || i < 0 || i >= (int64_t)t->T.rank_keys.size()) return GZ_E_INVALID;
+    if (utf8) *utf8 = (const uint8_t*)t->T.rank_keys[i].data();
+    if (len) *len = (int32_t)t->T.rank_keys[i].size();
+    if (n_fields) *n_fields = t->T.rank_nfields[i];
+    if (rank) *rank = t->T.rank_vals[i];
+    return GZ_OK;
+}
+
+int gz_host_tables_symbol(gz_host_tables* t, int32_t symbol, const uint8_t** utf8, int32_t* len)
+{
+    if (!t || symbol < 0 || symbol >= (int32_t)t->T.symbols.size()) return GZ_E_INVALID;
+    if (utf8) *utf8 = (const uint8_t*)t->T.symbols[symbol].data();
+    if (len) *len = (int32_t)t->T.symbols[symbol].size();
+    return GZ_OK;
+}
+
+}  // extern "C"

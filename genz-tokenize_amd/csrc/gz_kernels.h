@@ -85,8 +85,9 @@ void gz_launch_decode(const GzDecTable& D, const int32_t* ids, const int64_t* ro
 
 // text pre-pass (gz_preproc.inc): one filter over documents that sit in the slots of a packed text
 struct GzPpArgs {
-    const uint8_t* in; const int64_t* in_off;   // slot of document d = in[in_off[d] - in_off[0] ...
+    const uint8_t* in; const int64_t* in_off;   // slot of document d = in[in_off[d] - in_off[0] ... (in_abs: see below)
     const int64_t* in_len;                      // ... its current length (nullptr: the whole slot, in_off[d+1] - in_off[d])
+    int32_t in_abs;                             // 1: `in` is the caller's text, document d at in[in_off[d] ...] (absolute, as gz_encode_batch_device)
     int64_t n_docs;
     uint8_t* out;                               // pass 1: same slots, another buffer
     int64_t* out_len;                           // pass 1: the new lengths

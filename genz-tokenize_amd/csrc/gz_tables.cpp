@@ -102,11 +102,12 @@ size_t count_cps(const std::string& s)
 
 char32_t first_cp(const std::string& s)
 {
-    unsigned char b = s[0];
+    auto u = [&](size_t i) -> uint32_t { return (unsigned char)s[i]; };     // (bytes as unsigned: no signed shifts)
+    const uint32_t b = u(0);
     if (b < 0x80) return b;
-    if (b < 0xE0) return ((b & 0x1F) << 6) | (s[1] & 0x3F);
-    if (b < 0xF0) return ((b & 0x0F) << 12) | ((s[1] & 0x3F) << 6) | (s[2] & 0x3F);
-    return ((b & 0x07) << 18) | ((s[1] & 0x3F) << 12) | ((s[2] & 0x3F) << 6) | (s[3] & 0x3F);
+    if (b < 0xE0) return ((b & 0x1Fu) << 6) | (u(1) & 0x3Fu);
+    if (b < 0xF0) return ((b & 0x0Fu) << 12) | ((u(1) & 0x3Fu) << 6) | (u(2) & 0x3Fu);
+    return ((b & 0x07u) << 18) | ((u(1) & 0x3Fu) << 12) | ((u(2) & 0x3Fu) << 6) | (u(3) & 0x3Fu);
 }
 
 bool ends_with(const std::string& s, const char* suf)

@@ -23,10 +23,10 @@ GZ_PP_HTML, GZ_PP_UNICODE, GZ_PP_PUNCT, GZ_PP_EMOJI, GZ_PP_URL = 1, 2, 3, 4, 5
 # every symbol include/genz_tokenize.h declares (tests/test_abi.py checks the export list against the header)
 SYMBOLS = [
     "gz_version", "gz_create", "gz_destroy", "gz_last_error", "gz_load_tables", "gz_table_info",
-    "gz_vocab_entry", "gz_merge_entry", "gz_encode_batch", "gz_encode_batch_device", "gz_encode_batch_device_h", "gz_sync",
+    "gz_vocab_entry", "gz_merge_entry", "gz_encode_batch", "gz_encode_batch_csr", "gz_host_alloc", "gz_host_free", "gz_encode_batch_device", "gz_encode_batch_device_h", "gz_sync",
     "gz_word_token_counts", "gz_bpe_word", "gz_symbol_utf8", "gz_device_alloc", "gz_device_free", "gz_memcpy_h2d", "gz_memcpy_d2h",
     "gz_timing", "gz_timing_history", "gz_decoder_snapshot", "gz_decode_batch", "gz_decode_batch_device", "gz_preprocess_batch",
-    "gz_preprocess_batch_device", "gz_block_create", "gz_block_release", "gz_block_dlpack", "gz_exchange_select", "gz_comm_unique_id", "gz_comm_init", "gz_gather_rows", "gz_compact_rows", "gz_expand_rows", "gz_compact_rows16", "gz_expand_rows16",
+    "gz_preprocess_batch_device", "gz_block_create", "gz_block_release", "gz_block_dlpack", "gz_dlpack_capsule_destructor", "gz_exchange_select", "gz_comm_unique_id", "gz_comm_init", "gz_gather_rows", "gz_compact_rows", "gz_expand_rows", "gz_compact_rows16", "gz_expand_rows16",
     "gz_host_tables_create", "gz_host_tables_destroy", "gz_host_tables_array", "gz_host_tables_vocab_entry",
     "gz_host_tables_merge_entry", "gz_host_tables_symbol",
 ]
@@ -64,6 +64,9 @@ def load_library():
     L.gz_encode_batch.argtypes = enc
     L.gz_encode_batch_device.argtypes = enc
     L.gz_encode_batch_device_h.argtypes = enc + [vp, vp]
+    L.gz_encode_batch_csr.argtypes = [vp, vp, vp, i64, i32, u32, vp, i64, i32, vp, P(i64)]
+    L.gz_host_alloc.argtypes = [vp, sz, P(vp)]
+    L.gz_host_free.argtypes = [vp, vp]
     L.gz_sync.argtypes = [vp]
     L.gz_word_token_counts.argtypes = [vp, C.c_int, vp, i64, vp, P(i64)]
     L.gz_bpe_word.argtypes = [vp, vp, i64, vp, i64]; L.gz_bpe_word.restype = i64
@@ -82,6 +85,7 @@ def load_library():
     L.gz_block_create.argtypes = [vp, vp, P(vp)]
     L.gz_block_release.argtypes = [vp]; L.gz_block_release.restype = None
     L.gz_block_dlpack.argtypes = [vp, i32, vp, i32, i32]; L.gz_block_dlpack.restype = vp
+    L.gz_dlpack_capsule_destructor.argtypes = [vp]; L.gz_dlpack_capsule_destructor.restype = None
     L.gz_exchange_select.argtypes = [vp, C.c_int]
     L.gz_comm_unique_id.argtypes = [vp]
     L.gz_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
@@ -98,7 +102,8 @@ def load_library():
     L.gz_host_tables_symbol.argtypes = [vp, i32, P(vp), P(i32)]
     for name in SYMBOLS:
         fn = getattr(L, name)
-        if name not in ("gz_destroy", "gz_last_error", "gz_bpe_word", "gz_host_tables_destroy", "gz_block_release", "gz_block_dlpack"):
+        if name not in ("gz_destroy", "gz_last_error", "gz_bpe_word", "gz_host_tables_destroy", "gz_block_release", "gz_block_dlpack",
+                        "gz_dlpack_capsule_destructor"):
             fn.restype = C.c_int
     _lib = L
     return L
@@ -231,6 +236,42 @@ class Context:
         if is_pair:
             out.update(token_type_ids=tt[:total], sequence_id=seq[:total], pair_len=pair_len[:2 * n].reshape(n, 2))
         return out
+
+    # ---- host buffers in, CSR out, copies overlapped with the kernels ---------------------------------------------------
+    def pinned_empty(self, shape, dtype=np.uint8) -> np.ndarray:
+        """A numpy array in page-locked host memory (gz_host_alloc): H2D / D2H copies of it are real DMA.  The memory is
+        returned when the array (and every view of it) is gone."""
+        dtype = np.dtype(dtype)
+        n = int(np.prod(shape, dtype=np.int64))
+        p = C.c_void_p()
+        self._check(self.lib.gz_host_alloc(self.handle, max(n * dtype.itemsize, 1), C.byref(p)))
+        buf = (C.c_char * max(n * dtype.itemsize, 1)).from_address(p.value)
+        lib, handle, addr = self.lib, self.handle, p.value
+        import weakref
+        arr = np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
+        weakref.finalize(buf, lambda: lib.gz_host_free(handle, C.c_void_p(addr)))
+        return arr
+
+    def encode_csr(self, text: np.ndarray, text_off: np.ndarray, max_len: int, bits: int = 16, extra_flags: int = 0,
+                   tokens: np.ndarray | None = None, n_real: np.ndarray | None = None):
+        """gz_encode_batch_csr: (tokens[total] uint16|int32, n_real[N] int32).  `tokens` / `n_real` may be supplied
+        (e.g. pinned); tokens must hold min(N * max_len, bytes + 2 N) entries to be safe."""
+        n = len(text_off) - 1
+        text = np.ascontiguousarray(text, dtype=np.uint8)
+        text_off = np.ascontiguousarray(text_off, dtype=np.int64)
+        tb = int(text_off[-1] - text_off[0]) if n else 0
+        cap = min(n * int(max_len), tb + 2 * n)
+        dt = np.uint16 if bits == 16 else np.int32
+        if tokens is None:
+            tokens = np.empty(max(cap, 1), dtype=dt)
+        if n_real is None:
+            n_real = np.empty(max(n, 1), dtype=np.int32)
+        assert tokens.dtype == dt and n_real.dtype == np.int32 and tokens.flags["C_CONTIGUOUS"] and n_real.flags["C_CONTIGUOUS"]
+        total = C.c_int64()
+        self._check(self.lib.gz_encode_batch_csr(self.handle, _ptr(text), _ptr(text_off), n, int(max_len),
+                                                 GZ_PADDING | GZ_TRUNCATION | extra_flags, _ptr(tokens), tokens.size, bits,
+                                                 _ptr(n_real), C.byref(total)))
+        return tokens[:total.value], n_real[:n]
 
     def word_token_counts(self, which_text: int, n_docs: int, capacity: int):
         """(counts[int32, words], doc_first[int64, n_docs+1]) of the last encode call."""

@@ -5,8 +5,8 @@ cross-document state), so the batch shards by contiguous document ranges and the
 gather of the `[n_r, max_len]` int32 blocks (input_ids, attention_mask) to the root rank, done by the C ABI's
 `gz_gather_rows` (grouped ncclSend/ncclRecv over xGMI: every peer uses its own link to the root).
 
-The planning and bookkeeping live here so that they can be exercised on CPU with `gloo` (tests/test_distributed.py)
-through the `Transport` interface; on GPUs the transport is RCCL inside the C library.
+The shard planning lives here; the transport is RCCL inside the C library (`RcclTransport`).  The CPU test-suite
+exercises the same gatherv contract over `gloo` with a stand-in transport kept under tests/ (tests/gloo_transport.py).
 """
 from __future__ import annotations
 
@@ -31,18 +31,10 @@ def plan_shards(offsets: np.ndarray, world: int) -> List[Tuple[int, int]]:
     return [(cuts[r], cuts[r + 1]) for r in range(world)]
 
 
-class Transport:
-    """gatherv of int32 row blocks to a root."""
-
-    rank: int
-    world: int
-
-    def gather_rows(self, local, rows_per_rank: Sequence[int], row_len: int, root: int = 0):
-        raise NotImplementedError
-
-
-class RcclTransport(Transport):
-    """Device-resident gather through gz_gather_rows.  `local` and the returned handle are device pointers."""
+class RcclTransport:
+    """Device-resident gatherv of int32 row blocks to a root rank through gz_gather_rows (grouped ncclSend / ncclRecv:
+    every peer's block crosses its own xGMI link).  `d_local` / `d_recv` are device pointers; rows_per_rank[r] rows of
+    `row_len` int32 come from rank r and land at the root in rank order."""
 
     def __init__(self, ctx, rank: int, world: int, uid: bytes):
         self.ctx, self.rank, self.world = ctx, rank, world
@@ -51,32 +43,3 @@ class RcclTransport(Transport):
     def gather_rows(self, d_local: int, rows_per_rank, row_len, root=0, d_recv: int = 0):
         self.ctx.gather_rows(d_local, int(rows_per_rank[self.rank]), row_len, d_recv, rows_per_rank, root)
         return d_recv
-
-
-class GlooTransport(Transport):
-    """Same contract over torch.distributed point-to-point on CPU tensors (tests only)."""
-
-    def __init__(self, rank: int, world: int):
-        self.rank, self.world = rank, world
-
-    def gather_rows(self, local: np.ndarray, rows_per_rank, row_len, root=0):
-        import torch
-        import torch.distributed as dist
-        local = np.ascontiguousarray(local, dtype=np.int32).reshape(-1, row_len)
-        assert local.shape[0] == rows_per_rank[self.rank]
-        if self.rank != root:
-            if local.size:
-                dist.send(torch.from_numpy(local), dst=root)
-            return None
-        out = np.empty((int(sum(rows_per_rank)), row_len), dtype=np.int32)
-        row0 = 0
-        for q in range(self.world):
-            k = int(rows_per_rank[q])
-            if q == root:
-                out[row0:row0 + k] = local
-            elif k:
-                buf = torch.empty((k, row_len), dtype=torch.int32)
-                dist.recv(buf, src=q)
-                out[row0:row0 + k] = buf.numpy()
-            row0 += k
-        return out

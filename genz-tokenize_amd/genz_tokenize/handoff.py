@@ -57,8 +57,9 @@ class DeviceArray:
         mt = self._ctx.lib.gz_block_dlpack(self._block, len(self.shape), C.cast(shape, C.c_void_p), code, self.dtype.itemsize * 8)
         if not mt:
             raise MemoryError("gz_block_dlpack failed")
-        # no capsule destructor: a capsule that is never consumed keeps its reference (and the block) alive
-        return _api.PyCapsule_New(mt, b"dltensor", None)
+        # the capsule's destructor lives in the C library (a Python callback could run during interpreter shutdown):
+        # a capsule that is never consumed gives its reference back, a consumed one is left to the consumer's deleter
+        return _api.PyCapsule_New(mt, b"dltensor", C.cast(self._ctx.lib.gz_dlpack_capsule_destructor, C.c_void_p))
 
     def free(self):
         """Drop this object's reference; tensors already exported keep the memory alive."""

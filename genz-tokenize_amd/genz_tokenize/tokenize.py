@@ -303,6 +303,37 @@ class Tokenize(object):
                              0 if word_table else _native.GZ_NO_WORD_TABLE)
         return self._shape(r, len(offsets) - 1)
 
+    def encode_packed_csr(self, text_u8: np.ndarray, offsets: np.ndarray, max_len: int, word_table: bool = True):
+        """The fast host path for large batches: `__call__(text, max_len=max_len)` over packed UTF-8, with the result in
+        CSR form -- dict(tokens [total] (uint16 when every id fits, else int32), n_real [N], row_off [N+1], max_len,
+        pad_id).  Only the text and the rows' real entries cross PCIe (the copies overlap the kernels); `csr_to_dense`
+        rebuilds the [N, max_len] input_ids / attention_mask of `encode_packed` on the host when they are wanted."""
+        self._sync_tables()
+        if max_len is None or int(max_len) < 1:
+            raise ValueError("encode_packed_csr needs max_len >= 1 (rows are cut to max_len)")
+        bits = 16 if self.vocab_size() <= 65536 and max(self._special_ids()) < 65536 and min(self._special_ids()) >= 0 else 32
+        try:
+            tokens, n_real = self._ctx.encode_csr(text_u8, offsets, int(max_len), bits, 0 if word_table else _native.GZ_NO_WORD_TABLE)
+        except _native.GzError as e:
+            if bits == 16 and e.code == _native.GZ_E_LIMIT:              # an id collision pushed an id past 65535
+                tokens, n_real = self._ctx.encode_csr(text_u8, offsets, int(max_len), 32, 0 if word_table else _native.GZ_NO_WORD_TABLE)
+            else:
+                raise
+        row_off = np.zeros(len(n_real) + 1, dtype=np.int64)
+        np.cumsum(n_real, out=row_off[1:])
+        return dict(tokens=tokens, n_real=n_real, row_off=row_off, max_len=int(max_len), pad_id=self._special_ids()[0])
+
+    @staticmethod
+    def csr_to_dense(csr):
+        """(input_ids, attention_mask) [N, max_len] int32 of a `encode_packed_csr` result: rows padded with the pad id
+        (tokenize.py:141-146), mask = ids != pad (:148-152)."""
+        n, L = len(csr["n_real"]), csr["max_len"]
+        ids = np.full((n, L), csr["pad_id"], dtype=np.int32)
+        cols = np.arange(L, dtype=np.int64)[None, :]
+        keep = cols < csr["n_real"][:, None]
+        ids[keep] = csr["tokens"].astype(np.int32, copy=False)
+        return ids, (ids != csr["pad_id"]).astype(np.int32)
+
     def encode_to_device(self, texts: Sequence[str], pair_texts: Optional[Sequence[str]] = None, max_len: int = 128):
         """Batch `__call__` (padding=True, truncation=True) whose [N, max_len] int32 outputs STAY in HBM: a dict with the field names
         of the reference's DataCollection (models/bert/dataset.py:7-28) -- input_ids, attention_mask and, with pair

@@ -143,22 +143,37 @@ int64_t gz_bpe_word(gz_ctx *ctx, const uint8_t *word_utf8, int64_t len, int32_t 
 int  gz_symbol_utf8(gz_ctx *ctx, int32_t symbol, const uint8_t **utf8, int32_t *len);
 
 /* Device memory helpers so that a Python host needs nothing but ctypes (no torch in the product path). */
+/* Host path with the copies overlapped (SURVEY.md 8(d) timing (ii); replaces a loop of Tokenize.__call__ with
+ * max_len, padding=True, truncation=True over host strings, tokenize.py:184-259): the result comes back in CSR form --
+ * n_real[d] = entries of row d after truncation (tokenize.py:141-146), and the rows' real entries back to back in
+ * `tokens` (uint16 when bits == 16 and every id of the vocabulary fits, else int32; capacity in entries).  The dense
+ * [N, max_len] input_ids / attention_mask are `row padded with the pad id` and `1 for the first n_real[d] positions`
+ * unless a real token equals the pad id (then mask = ids != pad, :148-152): a caller rebuilds them only where needed.
+ * The batch is cut into sub-batches: text H2D, kernels and the D2H of the compact rows run on three streams.
+ * `text` / `tokens` / `n_real` from gz_host_alloc (pinned) make both copies true DMA; pageable memory works, slower.
+ * *total = entries written (or needed: GZ_E_CAPACITY).  Single texts only. */
+int  gz_host_alloc(gz_ctx *ctx, size_t bytes, void **ptr);
+int  gz_host_free(gz_ctx *ctx, void *ptr);
+int  gz_encode_batch_csr(gz_ctx *ctx, const uint8_t *text, const int64_t *text_off, int64_t n_docs, int32_t max_len,
+                         uint32_t flags, void *tokens, int64_t capacity, int32_t bits, int32_t *n_real, int64_t *total);
+
 int  gz_device_alloc(gz_ctx *ctx, size_t bytes, void **dptr);
 int  gz_device_free(gz_ctx *ctx, void *dptr);
 int  gz_memcpy_h2d(gz_ctx *ctx, void *dst_device, const void *src_host, size_t bytes);
 int  gz_memcpy_d2h(gz_ctx *ctx, void *dst_host, const void *src_device, size_t bytes);
 
 /* With GZ_TIMING: milliseconds (HIP events on the context's stream) of the kernels of the LAST encode call:
- * out[0] = encode kernel (scan + BPE + lookup + frame/pad/mask), out[1] = ragged finalize, out[2] = pair
- * type-id kernel, out[3] = whole call on the stream.  Unused slots are 0. */
+ * out[0] = the kernel pipeline of the call (split: brk / classify / scan / docw0; words; misses: scan / miss / miss_wide /
+ * long; rows: rows1 | rows | assemble), out[1] = ragged finalize (row lengths, scan, copy), out[2] = pair type-id
+ * kernel, out[3] = whole call on the stream.  Unused slots are 0. */
 int  gz_timing(gz_ctx *ctx, double out_ms[4]);
 /* GZ_TIMING calls can be chained without gz_sync in between (a dense call followed by a call that brings host copies
  * of its offsets is enqueued right behind it).  gz_timing_history synchronises and returns the duration of the main
- * kernels of the last (up to 64, up to `max`) timed calls, oldest first, then forgets them. */
+ * kernels of the last (up to 1024, up to `max`) timed calls, oldest first, then forgets them. */
 int  gz_timing_history(gz_ctx *ctx, double *out_ms, int32_t max, int32_t *n_out);
 
 /* Offline / diagnostic table build on the HOST only (no GPU needed): the same builder gz_load_tables runs, with
- * the integer tables it would upload exposed read-only.  `which`: 0 pair hash (uint64 x2 [slots]: key<<24|rank, merged symbol), 1 merges
+ * the integer tables it would upload exposed read-only.  `which`: 0 pair hash (uint32 x4 [slots]: left, right, merged symbol, rank; left = 0xFFFFFFFF: empty slot), 1 merges
  * (uint32 x4 [n_lines]: left,right,merged,0), 2 symbol ids (int32 x2 [n_symbols]: non-final, final), 3 BMP code
  * point table (uint32 x2 [65536]: plain, final), 4 astral table (uint32 x4 [slots]: cp,plain,final,0; may be
  * empty), 5 special ids (int32 [5]).  Pointers stay valid until gz_host_tables_destroy. */
@@ -182,7 +197,8 @@ int  gz_host_tables_symbol(gz_host_tables *t, int32_t symbol, const uint8_t **ut
  *   out      UTF-8 bytes of all rows back to back; out_off[n_rows+1] their byte offsets
  *   Returns GZ_E_CAPACITY when `capacity` is too small; out_off is valid then (out_off[n_rows] = bytes needed).
  * gz_decode_batch_device: the same with ids / row_off / out / out_off resident in HBM (total_host = bytes needed or
- *   written); out_dev may be NULL to size the output only. */
+ *   written); out_dev may be NULL to size the output only.  As in every *_device entry point the offsets are
+ *   ABSOLUTE from the base pointer: row r = ids_dev[row_off_dev[r] .. row_off_dev[r+1]), row_off_dev[0] need not be 0. */
 int  gz_decoder_snapshot(gz_ctx *ctx);
 int  gz_decode_batch(gz_ctx *ctx, const int32_t *ids, const int64_t *row_off, int64_t n_rows, const uint8_t *unk, int32_t unk_len,
                      uint8_t *out, int64_t capacity, int64_t *out_off);
@@ -200,7 +216,9 @@ int  gz_decode_batch_device(gz_ctx *ctx, const int32_t *ids_dev, const int64_t *
  * be handed straight to it).  No filter grows a document, so capacity = input bytes always suffices; GZ_E_CAPACITY
  * is returned otherwise and out_off is still valid.  No tables are needed.
  * gz_preprocess_batch_device: the same with text / offsets / outputs resident in HBM; text_bytes = bytes of the input
- * text; *total_host = bytes written (or needed); out_dev may be NULL to size the output only. */
+ * text = text_off_dev[n_docs] - text_off_dev[0]; *total_host = bytes written (or needed); out_dev may be NULL to size the
+ * output only.  Offsets are ABSOLUTE from the base pointer (document d = text_dev[text_off_dev[d] ..), exactly like
+ * gz_encode_batch_device; text_off_dev[0] need not be 0.  The output offsets start at 0. */
 #define GZ_PP_HTML    1
 #define GZ_PP_UNICODE 2
 #define GZ_PP_PUNCT   3
@@ -222,6 +240,10 @@ typedef struct gz_block gz_block;
 int   gz_block_create(gz_ctx *ctx, void *dptr, gz_block **out);
 void  gz_block_release(gz_block *block);
 void *gz_block_dlpack(gz_block *block, int32_t ndim, const int64_t *shape, int32_t dtype_code, int32_t dtype_bits);
+/* Destructor for a PyCapsule named "dltensor" that wraps gz_block_dlpack's result (pass its address to PyCapsule_New):
+ * a capsule nobody consumed gives its reference to the block back; a consumed one ("used_dltensor") is left alone.
+ * (No reference counterpart: models/bert/dataset.py:7-28 builds tf tensors from Python lists.) */
+void gz_dlpack_capsule_destructor(void *capsule);
 
 /* Multi-GPU exchange step (one process per GPU, RCCL over xGMI).  rank 0 creates an id, every rank calls
  * gz_comm_init with it; gz_gather_rows sends each rank's [n_rows, row_len] int32 device block to `root`,

@@ -36,7 +36,9 @@ def _worker(rank, world, port, q):
     import torch.distributed as dist
     import corpus
     import gz_oracle as O
-    from genz_tokenize.distributed import GlooTransport, plan_shards
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from genz_tokenize.distributed import plan_shards
+    from gloo_transport import GlooTransport
     dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port, rank=rank, world_size=world)
     try:
         t = O.Tables(open(corpus.VOCAB_PATH, "rb").read(), open(corpus.BPE_PATH, "rb").read())

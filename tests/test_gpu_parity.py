@@ -169,6 +169,131 @@ def test_g5_reference_hashes_custom_tables(sampler, tmp_path):
     _check_hashes(t, e, text, offs, False)
 
 
+def test_cfg4_shard_digests_full_size(tok, sampler):
+    """BASELINE configs[3]: one whole shard (1.25 M documents, seed 100 + s) of the fixed 10 M-document job against its
+    committed digests (C oracle over the whole shard; the reference itself over the first 20 000 documents).  bench.py
+    checks all eight shards on every run; here shard 5."""
+    g5 = json.load(open(os.path.join(GOLDEN, "g5_hashes.json")))
+    e = g5["cfg4_shard5"]
+    text, offs, L = corpus.config_corpus(4, n_docs=e["n_docs"], seed=e["seed"], sampler=sampler)
+    assert L == e["max_len"] and int(offs[-1]) == e["input_bytes"]
+    _check_hashes(tok, e, text, offs, True)
+    r = e["ref_prefix"]
+    out = tok.encode_packed(text[:int(offs[r["n_docs"]])], offs[:r["n_docs"] + 1], max_len=L)
+    for k, lo in enumerate(range(0, r["n_docs"], r["block"])):
+        assert hashlib.sha256(out["input_ids"][lo:lo + r["block"]].tobytes()).hexdigest() == r["ids_sha256"][k]
+        assert hashlib.sha256(out["attention_mask"][lo:lo + r["block"]].tobytes()).hexdigest() == r["mask_sha256"][k]
+
+
+def test_cfg5_full_size_padded_and_unpadded(sampler, tmp_path):
+    """BASELINE configs[4] at FULL size: all 50 000 documents (<= 4 000 characters) on the custom 100 k-entry vocabulary,
+    max_len=1024 pad+trunc AND unpadded (max_len=None), against the C-oracle digests; the first 300 documents also
+    against digests computed by the reference (Tokenize.fromFile) on the same documents."""
+    from genz_tokenize import Tokenize
+    e = json.load(open(os.path.join(GOLDEN, "g5_hashes.json")))["cfg5_50k"]
+    v, b = corpus.custom_tables()
+    (tmp_path / "v").write_bytes(v); (tmp_path / "b").write_bytes(b)
+    t = Tokenize.fromFile(str(tmp_path / "v"), str(tmp_path / "b"))
+    text, offs, L = corpus.config_corpus(5, n_docs=e["n_docs"], sampler=sampler)
+    assert int(offs[-1]) == e["input_bytes"]
+    for name in ("padded", "unpadded"):
+        d = e[name]
+        out = t.encode_packed(text, offs, max_len=d["max_len"])
+        ids, mask, ro = out["input_ids"].reshape(-1), out["attention_mask"].reshape(-1), out["row_off"]
+        for k, lo in enumerate(range(0, e["n_docs"], e["block"])):
+            a, z = int(ro[lo]), int(ro[min(lo + e["block"], e["n_docs"])])
+            assert hashlib.sha256(ids[a:z].tobytes()).hexdigest() == d["ids_sha256"][k], (name, "ids block", k)
+            assert hashlib.sha256(mask[a:z].tobytes()).hexdigest() == d["mask_sha256"][k], (name, "mask block", k)
+        assert int(mask.sum()) == d["n_tokens"]
+        r = d["ref_prefix"]
+        for k, lo in enumerate(range(0, r["n_docs"], r["block"])):
+            a, z = int(ro[lo]), int(ro[lo + r["block"]])
+            assert hashlib.sha256(ids[a:z].tobytes()).hexdigest() == r["ids_sha256"][k], (name, "reference block", k)
+            assert hashlib.sha256(mask[a:z].tobytes()).hexdigest() == r["mask_sha256"][k], (name, "reference block", k)
+
+
+def test_csr_host_path_matches_dense(tok, sampler, tmp_path):
+    """gz_encode_batch_csr (sub-batches, copies overlapped with the kernels, only real entries cross PCIe): the rows it
+    returns, padded back on the host, are the dense path's input_ids / attention_mask -- several sub-batches, pinned and
+    pageable buffers, empty documents, a 1-document batch, and 32-bit entries for a vocabulary with ids above 65535."""
+    from genz_tokenize import Tokenize
+    text, offs, L = corpus.config_corpus(3, n_docs=300_000, seed=17, sampler=sampler)       # ~86 MB: 3 sub-batches
+    dense = tok.encode_packed(text, offs, max_len=L)
+    csr = tok.encode_packed_csr(text, offs, max_len=L)
+    assert csr["tokens"].dtype == np.uint16
+    ids, mask = tok.csr_to_dense(csr)
+    assert np.array_equal(ids, dense["input_ids"]) and np.array_equal(mask, dense["attention_mask"])
+    assert np.array_equal(csr["n_real"], dense["n_real"])
+    # pinned input and output buffers (the bench's device end-to-end timing uses these)
+    ctx = tok._ctx
+    ptext = ctx.pinned_empty(len(text), np.uint8); ptext[:] = text
+    ptok = ctx.pinned_empty(min(len(offs) * L, len(text) + 2 * len(offs)), np.uint16)
+    pnr = ctx.pinned_empty(len(offs) - 1, np.int32)
+    t2, n2 = ctx.encode_csr(ptext, offs, L, 16, tokens=ptok, n_real=pnr)
+    assert np.array_equal(t2, csr["tokens"]) and np.array_equal(n2, csr["n_real"])
+    # ragged edge cases: empty documents, whitespace only, one document, a tiny max_len
+    docs = ["", "  ", "a", "", "xin ch\u00e0o c\u00e1c b\u1ea1n", "", "zzzqqqxx " * 40, ""]
+    enc = [d.encode() for d in docs]
+    o = np.zeros(len(enc) + 1, np.int64); np.cumsum([len(e) for e in enc], out=o[1:])
+    t = np.frombuffer(b"".join(enc) + b" ", np.uint8)[:int(o[-1])]
+    for ml in (1, 2, 7, 64):
+        d = tok.encode_packed(t, o, max_len=ml)
+        i2, m2 = tok.csr_to_dense(tok.encode_packed_csr(t, o, max_len=ml))
+        assert np.array_equal(i2, d["input_ids"]) and np.array_equal(m2, d["attention_mask"]), ml
+    one = tok.encode_packed_csr(t[:0], np.zeros(2, np.int64), max_len=8)
+    assert one["tokens"].tolist() == [1, 2] and one["n_real"].tolist() == [2]
+    # ids above 65535: 32-bit entries
+    v, b = corpus.custom_tables()
+    (tmp_path / "v").write_bytes(v); (tmp_path / "b").write_bytes(b)
+    t5 = Tokenize.fromFile(str(tmp_path / "v"), str(tmp_path / "b"))
+    text5, offs5, L5 = corpus.config_corpus(5, n_docs=200, sampler=sampler)
+    c5 = t5.encode_packed_csr(text5, offs5, max_len=L5)
+    assert c5["tokens"].dtype == np.int32
+    d5 = t5.encode_packed(text5, offs5, max_len=L5)
+    i5, m5 = t5.csr_to_dense(c5)
+    assert np.array_equal(i5, d5["input_ids"]) and np.array_equal(m5, d5["attention_mask"])
+
+
+def test_device_entry_points_take_absolute_offsets(tok, oracle_tables, sampler):
+    """gz_preprocess_batch_device and gz_decode_batch_device read their input like gz_encode_batch_device: offsets are
+    absolute from the base pointer, the first one need not be 0."""
+    ctx = tok._ctx
+    text, offs, L = corpus.config_corpus(2, n_docs=500, seed=41, sampler=sampler)
+    offs = np.ascontiguousarray(offs, dtype=np.int64)
+    lo, n = 137, 300                                                   # documents [137, 437) of the packed text
+    sub = np.ascontiguousarray(offs[lo:lo + n + 1])
+    assert sub[0] != 0
+    nbytes = int(sub[-1] - sub[0])
+    d_text = ctx.alloc(len(text) + 64); ctx.h2d(d_text, text)
+    d_off = ctx.alloc(8 * (n + 1)); ctx.h2d(d_off, sub)
+    d_out = ctx.alloc(nbytes + 64); d_oo = ctx.alloc(8 * (n + 1))
+    kept = ctx.preprocess_device([3, 4], d_text, d_off, n, nbytes, d_out, nbytes, d_oo)        # punct, emoji
+    got = np.empty(kept, np.uint8); ctx.d2h(got, d_out)
+    oo = np.empty(n + 1, np.int64); ctx.d2h(oo, d_oo)
+    raw = text.tobytes()
+    want = [O.preprocess(raw[offs[lo + i]:offs[lo + i + 1]].decode(), ["punct", "emoji"]) for i in range(n)]
+    assert [got[oo[i]:oo[i + 1]].tobytes().decode() for i in range(n)] == want
+    # decode: rows [lo, lo + n) of a packed id array
+    enc = tok.encode_packed(text, offs, max_len=None)
+    ids, ro = enc["input_ids"], np.ascontiguousarray(enc["row_off"], dtype=np.int64)
+    rsub = np.ascontiguousarray(ro[lo:lo + n + 1])
+    assert rsub[0] != 0
+    tok.decode_batch([[1, 2]])                                            # (takes the decoder snapshot)
+    d_ids = ctx.alloc(ids.nbytes + 64); ctx.h2d(d_ids, ids)
+    d_ro = ctx.alloc(8 * (n + 1)); ctx.h2d(d_ro, rsub)
+    d_do = ctx.alloc(8 * (n + 1))
+    unk = tok.unk_token.encode()
+    need = ctx.decode_device(d_ids, d_ro, n, unk, 0, 0, d_do)
+    d_txt = ctx.alloc(need + 64)
+    ctx.decode_device(d_ids, d_ro, n, unk, d_txt, need, d_do)
+    txt = np.empty(need, np.uint8); ctx.d2h(txt, d_txt)
+    do = np.empty(n + 1, np.int64); ctx.d2h(do, d_do)
+    want = [O.decode(ids[ro[lo + i]:ro[lo + i + 1]].tolist(), oracle_tables) for i in range(n)]
+    assert [txt[do[i]:do[i + 1]].tobytes().decode() for i in range(n)] == want
+    for p in (d_text, d_off, d_out, d_oo, d_ids, d_ro, d_do, d_txt):
+        ctx.free(p)
+
+
 def _oracle_rows(t, text, offs, pairs, ml, pad, tr):
     raw = text.tobytes()
     docs = [raw[offs[i]:offs[i + 1]].decode("utf-8") for i in range(len(offs) - 1)]
@@ -303,6 +428,55 @@ def test_rccl_gather_rows_single_rank(tok):
     ctx.sync()
     back = np.zeros_like(rows)
     ctx.d2h(back, d_dst)
+    assert np.array_equal(back, rows)
+    ctx.free(d_src); ctx.free(d_dst)
+
+
+def _gpu_count():
+    import ctypes
+    try:
+        hip = ctypes.CDLL("libamdhip64.so")
+        n = ctypes.c_int(0)
+        return n.value if hip.hipGetDeviceCount(ctypes.byref(n)) == 0 else 0
+    except OSError:
+        return 0
+
+
+def test_rccl_gather_two_ranks(tmp_path):
+    """gz_gather_rows with world = 2: two fresh processes, one GPU each, uneven row counts, the exchange of call 0
+    overlapped with call 1 (gz_exchange_select(1)), root != peer offsets checked against the oracle at the root, and a
+    mismatched count refused before any RCCL group opens.  Needs two GPUs (RCCL refuses two ranks on one device:
+    "Duplicate GPU detected"); the driver's 8-GPU bench run covers the same path through bench.py's per-peer digests."""
+    import subprocess
+    import sys
+    if _gpu_count() < 2:
+        pytest.skip("needs 2 GPUs; RCCL refuses two ranks on one device")
+    child = os.path.join(os.path.dirname(os.path.abspath(__file__)), "gather_child.py")
+    procs = [subprocess.Popen([sys.executable, child, str(r), "2", str(tmp_path)]) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=240) == 0
+    for r in range(2):
+        assert (tmp_path / ("verdict_%d" % r)).read_text() == "ok"
+
+
+def test_gather_rows_refuses_bad_arguments_before_opening_a_group(tok):
+    """Count / pointer mistakes come back as GZ_E_INVALID without touching RCCL (a rank that fails inside an open group
+    hangs the others); the communicator keeps working afterwards."""
+    from genz_tokenize import _native
+    ctx = tok._ctx
+    ctx.comm_init(ctx.comm_unique_id(), 0, 1)
+    rows = np.arange(5 * 8, dtype=np.int32).reshape(5, 8)
+    d_src = ctx.alloc(rows.nbytes); d_dst = ctx.alloc(rows.nbytes)
+    ctx.h2d(d_src, rows)
+    for args in ((d_src, 4, 8, d_dst, [5], 0),        # local count != rows_per_rank[rank]
+                 (d_src, 5, 8, 0, [5], 0),            # root without a receive buffer
+                 (0, 5, 8, d_dst, [5], 0),            # rows to send, no send buffer
+                 (d_src, 5, 8, d_dst, [5], 1)):       # root out of range
+        with pytest.raises(_native.GzError):
+            ctx.gather_rows(*args)
+    ctx.gather_rows(d_src, 5, 8, d_dst, [5], 0)
+    ctx.sync()
+    back = np.zeros_like(rows); ctx.d2h(back, d_dst)
     assert np.array_equal(back, rows)
     ctx.free(d_src); ctx.free(d_dst)
 

@@ -96,3 +96,27 @@ def test_g4_loader_through_tables():
         for c in row["calls"]:
             _cmp_call(sim, c)
         H.close()
+
+
+def test_host_builder_under_sanitizers():
+    """SURVEY.md section 5 (race detection / sanitizers): the host table builder -- the code that parses untrusted
+    vocab / merge file bytes (loader rules L1-L8) and does the index arithmetic behind the device tables -- built with
+    g++ -fsanitize=address,undefined (`make -C genz-tokenize_amd/csrc asan`, no HIP involved) and driven through the C
+    ABI's gz_host_tables_* in a child process: the bundled tables, every G4 loader fixture, and a byte-level fuzz of
+    table files and special-token strings.  Any sanitizer report aborts the child."""
+    import os
+    import subprocess
+    import sys
+    from conftest import ROOT
+    csrc = os.path.join(ROOT, "genz-tokenize_amd", "csrc")
+    subprocess.run(["make", "-s", "-C", csrc, "asan"], check=True)
+    asan = subprocess.run(["gcc", "-print-file-name=libasan.so"], capture_output=True, text=True, check=True).stdout.strip()
+    if not os.path.isabs(asan) or not os.path.exists(asan):
+        pytest.skip("libasan.so not found next to gcc")
+    env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:halt_on_error=1",
+               UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "host_asan_child.py")], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "asan child ok" in r.stdout
+    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]

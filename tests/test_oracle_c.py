@@ -122,6 +122,38 @@ def test_c_g5_full(c_oracle, name):
     assert hi == e["ids_sha256"] and hm == e["mask_sha256"] and ntok == e["n_tokens"]
 
 
+def test_c_cfg4_shard_prefix_matches_the_reference(c_oracle):
+    """The per-shard digests of BASELINE configs[3] come from the C oracle (whole shard) AND from the reference (first
+    20 000 documents of the same shard): here the C oracle is run on that prefix of one shard and must reproduce the
+    reference's digests, and its first whole-shard block must reproduce the committed whole-shard digest."""
+    import corpus
+    e = json.load(open(os.path.join(GOLDEN, "g5_hashes.json")))["cfg4_shard5"]
+    text, offs, L = corpus.config_corpus(4, n_docs=e["n_docs"], seed=e["seed"])
+    text = np.ascontiguousarray(text); offs = np.ascontiguousarray(offs, dtype=np.int64)
+    assert int(offs[-1]) == e["input_bytes"]
+    r = e["ref_prefix"]
+    hi, hm, ntok = _hash_blocks(c_oracle, text, offs[:r["n_docs"] + 1], L, r["block"])
+    assert hi == r["ids_sha256"] and hm == r["mask_sha256"] and ntok == r["n_tokens"]
+    hi, hm, _ = _hash_blocks(c_oracle, text, offs[:e["block"] + 1], L, e["block"])
+    assert hi[0] == e["ids_sha256"][0] and hm[0] == e["mask_sha256"][0]
+
+
+def test_c_cfg5_50k_prefix_matches_the_reference():
+    """BASELINE configs[4] at full size: the C oracle on the first 300 of the 50 000 documents (custom tables) against
+    the reference's digests of the same documents, padded and unpadded."""
+    import corpus
+    e = json.load(open(os.path.join(GOLDEN, "g5_hashes.json")))["cfg5_50k"]
+    text, offs, L = corpus.config_corpus(5, n_docs=e["n_docs"])
+    text = np.ascontiguousarray(text); offs = np.ascontiguousarray(offs, dtype=np.int64)
+    assert int(offs[-1]) == e["input_bytes"]
+    v, b = corpus.custom_tables()
+    co = OC.COracle(v, b)
+    for name in ("padded", "unpadded"):
+        r = e[name]["ref_prefix"]
+        hi, hm, ntok = _hash_blocks(co, text, offs[:r["n_docs"] + 1], e[name]["max_len"], r["block"])
+        assert hi == r["ids_sha256"] and hm == r["mask_sha256"] and ntok == r["n_tokens"], name
+
+
 @pytest.mark.parametrize("pair", [False, True])
 def test_c_vs_python_noisy(c_oracle, oracle_tables, pair):
     import corpus
