@@ -45,6 +45,16 @@ PIPELINE = ("gz_brk, gz_classify, gz_scan32, gz_docw0, gz_words, gz_scan32 (miss
             "gz_rows1")
 
 
+def kernel_source_sha16():
+    """sha256 (first 16 hex digits) over the native sources: a PMC profile is only quoted for the build it was taken on."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "genz-tokenize_amd", "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".inc", ".h", ".cpp")):
+            h.update(name.encode()); h.update(open(os.path.join(d, name), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def host_cores():
     """Cores this process may really use: the affinity mask, capped by the cgroup CPU quota when there is one."""
     try:
@@ -570,7 +580,7 @@ def secondary(ctx, tok, flags, args, cfg2):
     traffic = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
-        if tj.get("pipeline") == PIPELINE:
+        if tj.get("pipeline") == PIPELINE and tj.get("source_sha16") == kernel_source_sha16():
             traffic = tj
     except Exception:  # noqa: BLE001
         pass
@@ -621,7 +631,7 @@ def secondary(ctx, tok, flags, args, cfg2):
                      "traffic": traffic["bytes_per_step"] if traffic else None,
                      "traffic_source": "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, summed over the "
                                        "launch's kernels; reads not corrected for the gfx950 half-count)" if traffic else
-                                       "none at this pipeline (profiles/r02_pmc_traffic.json absent or from another kernel list)"}}
+                                       "none for this build (profiles/r02_pmc_traffic.json absent or taken on other kernel sources)"}}
     # ---- the same step with the whole-word tables off: every word through the merge loop
     k2 = R.kernel_ms(flags | _native.GZ_NO_WORD_TABLE, reps=3)
     out["merge_loop_only"] = {"kernel_ms_avg": round(k2, 4), "MB_per_s_kernel": round(R.in_bytes / k2 / 1e3, 1)}

@@ -99,7 +99,8 @@ struct gz_ctx {
     int rank = 0, world = 1;
 
     DBuf t_words2, t_words0;
-    struct TextWs { DBuf brk, st, en, blkcnt, docw0, wtok, waux, mtok, mlist, blkmiss, blklong, tilecnt, wlist, grpblk; } tw[2][2];   // [slot][text]
+    struct TextWs { DBuf brk, st, en, blkcnt, docw0, wtok, waux, mtok, mlist, blkmiss, blklong, tilecnt, wlist, grpblk, lookback; } tw[2][2];
+    uint32_t lb_epoch = 0;               // call number of the chained scan (gz_split_kernel)   // [slot][text]
     hipStream_t stream2 = nullptr;       // sub-batches alternate between the two streams
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // exchange step (compact / gather / expand) on its own stream, so that it overlaps the next call's kernels
@@ -252,6 +253,7 @@ int sync_locked(gz_ctx* c)
         hipEventElapsedTime(&ms, c->ev[0], c->ev[3]); c->timing[3] = ms;
     }
     p.active = false;
+    if (c->h_flags[0]) return fail(c, GZ_E_HIP, "internal: the chained scan of gz_split_kernel timed out");
     if (c->h_flags[1]) return fail(c, GZ_E_CAPACITY, "ragged output larger than capacity");
     return GZ_OK;
 }
@@ -286,13 +288,18 @@ int setup_text(gz_ctx* c, gz_ctx::TextWs& W, DBuf& tiny, const uint8_t* tb, cons
         (rc2 = ensure(c, W.mtok, (size_t)(Bt + 32) * 4)) || (rc2 = ensure(c, W.mlist, (size_t)wmax * 16)) ||
         (rc2 = ensure(c, W.grpblk, (size_t)(wmax / 64 + 4) * 4)) ||
         (rc2 = ensure(c, W.blkmiss, (size_t)(X.nblk + 2) * 4)) || (rc2 = ensure(c, W.blklong, (size_t)(X.nblk + 2) * 4)) ||
-        (rc2 = ensure(c, W.tilecnt, (size_t)(X.nblk + 2) * 8)) || (rc2 = ensure(c, W.wlist, (size_t)(wmax + 2) * 4)))
+        (rc2 = ensure(c, W.tilecnt, (size_t)(X.nblk + 2) * 8)) || (rc2 = ensure(c, W.wlist, (size_t)(wmax + 8) * 4)) ||
+        (rc2 = ensure(c, W.lookback, (size_t)(X.nblk / 4 + 4) * 8)))
         return rc2;
     X.brk = (uint16_t*)W.brk.p; X.st = (uint16_t*)W.st.p; X.en = (uint16_t*)W.en.p;
     X.blkcnt = (uint32_t*)W.blkcnt.p; X.docw0 = (uint32_t*)W.docw0.p;
     X.wtok = (uint32_t*)W.wtok.p; X.waux = (uint32_t*)W.waux.p; X.mtok = (int32_t*)W.mtok.p;
     X.mlist = (uint4*)W.mlist.p; X.grpblk = (uint32_t*)W.grpblk.p; X.wmax = wmax; X.blkmiss = (uint32_t*)W.blkmiss.p;
-    X.blklong = (uint32_t*)W.blklong.p; X.tilecnt = (uint16_t*)W.tilecnt.p; X.wlist = (uint32_t*)W.wlist.p;
+    X.blklong = (uint32_t*)W.blklong.p; X.tilecnt = (uint16_t*)W.tilecnt.p;
+    X.ctl = (uint32_t*)W.wlist.p; X.wlist = X.ctl + 4;                        // (one memset clears both)
+    X.lookback = (uint64_t*)W.lookback.p;
+    X.epoch = ++c->lb_epoch;
+    if ((X.epoch & 0x3FFFFFFFu) == 0) X.epoch = ++c->lb_epoch;               // (0 is what a fresh allocation may hold)
     return GZ_OK;
 }
 
@@ -583,7 +590,7 @@ void gz_destroy(gz_ctx* c)
                     &c->w_nreal, &c->w_status, &c->w_raw, &c->w_arena, &c->w_flags, &c->w_word, &c->w_wordout})
         release(*b);
     for (auto& slot : c->tw) for (auto& t : slot)
-        for (DBuf* b : {&t.brk, &t.st, &t.en, &t.blkcnt, &t.docw0, &t.wtok, &t.waux, &t.mtok, &t.mlist, &t.blkmiss, &t.blklong, &t.tilecnt, &t.wlist, &t.grpblk}) release(*b);
+        for (DBuf* b : {&t.brk, &t.st, &t.en, &t.blkcnt, &t.docw0, &t.wtok, &t.waux, &t.mtok, &t.mlist, &t.blkmiss, &t.blklong, &t.tilecnt, &t.wlist, &t.grpblk, &t.lookback}) release(*b);
     for (auto& ev : c->ev) if (ev) hipEventDestroy(ev);
     for (auto& pr : c->ring) { if (pr[0]) hipEventDestroy(pr[0]); if (pr[1]) hipEventDestroy(pr[1]); }
     if (c->h_flags) hipHostFree(c->h_flags);

@@ -50,6 +50,9 @@ struct GzTextBufs {              // one text (A or B) of a batch and its per-cal
     uint32_t* blkmiss;           // [nblk+1] number of misses per block; scanned in place before gz_miss_kernel ([nblk] = total)
     uint32_t* grpblk;            // [words/64 + 2] block that holds miss number 64 g (written by the scan)
     int64_t wmax;                // upper bound of the number of words (sizes of the per-word arrays)
+    uint32_t* ctl;               // [4] zeroed per call: [1] ticket counter of gz_split_kernel; wlist == ctl + 4
+    uint64_t* lookback;          // [nblk / 4 + 2] chained-scan words of gz_split_kernel {status:2, call:30, value:32}; never cleared
+    uint32_t epoch;              // call number written into / expected in the chained-scan words
     uint32_t* blklong;           // [nblk] block holds a word for gz_long_kernel (zeroed per call)
     uint32_t* wlist;             // [0] count, then the words (indices) that need 32 or 64 lanes (zeroed count per call)
     uint16_t* tilecnt;           // [4 * nblk] word starts of the block that lie before each of its four 1-KiB tiles

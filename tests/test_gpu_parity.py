@@ -254,6 +254,22 @@ def test_csr_host_path_matches_dense(tok, sampler, tmp_path):
     assert np.array_equal(i5, d5["input_ids"]) and np.array_equal(m5, d5["attention_mask"])
 
 
+def test_fused_split_kernel_path():
+    """GZ_SPLIT=1 selects gz_split_kernel (classification + word lookup in ONE pass over the text, word indices from
+    a chained scan with decoupled look-back) instead of classify / scan / words.  It is not the default (measured
+    slower) but it is kept and must stay exact: the golden batches, a reference-digest corpus, the
+    noisy / pair / extreme-shape comparisons run again in a child process with the variable set."""
+    import subprocess
+    import sys
+    env = dict(os.environ, GZ_SPLIT="1")
+    here = os.path.abspath(__file__)
+    r = subprocess.run([sys.executable, "-m", "pytest", here, "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider", "-k",
+                        "g3_random_batched or cfg3_20k or noisy_corpus or noisy_pairs or extreme_batch or long_and_huge or chained"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
+
+
 def test_device_entry_points_take_absolute_offsets(tok, oracle_tables, sampler):
     """gz_preprocess_batch_device and gz_decode_batch_device read their input like gz_encode_batch_device: offsets are
     absolute from the base pointer, the first one need not be 0."""

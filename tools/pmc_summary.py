@@ -5,7 +5,8 @@ vals = collections.OrderedDict()
 for d in sys.argv[1:]:
     for f in glob.glob(d + '/**/*counter_collection.csv', recursive=True):
         for r in csv.DictReader(open(f)):
-            k = r['Kernel_Name'].split('(')[0]
+            k = r['Kernel_Name']
+            k = (k[5:] if k.startswith('void ') else k).split('(')[0]
             if not k.startswith('gz_'):
                 continue
             vals.setdefault(k, collections.OrderedDict())[r['Counter_Name']] = float(r['Counter_Value'])   # later rows win
