@@ -39,7 +39,7 @@ def main():
     import corpus
     from genz_tokenize import Tokenize, _native
     from genz_tokenize.distributed import plan_shards
-    tok = Tokenize(device=rank)
+    tok = Tokenize(device=int(os.environ.get("GZ_CHILD_DEVICE", rank)))        # (GZ_CHILD_DEVICE: both ranks on one GPU -- RCCL refuses that)
     tok._sync_tables()
     ctx = tok._ctx
     idf = os.path.join(rdv, "uid")
