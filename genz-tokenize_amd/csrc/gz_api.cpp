@@ -86,6 +86,12 @@ struct gz_ctx {
         bool timing = false;
         std::vector<GzAsmArgs> subs;   // sub-batches of the call (contiguous document ranges)
         int use_words = 0;             // bit 0: whole-word table; bits 8..: timing diagnostics (GZ_ABLATE)
+        // small batches: ONE fused launch (gz_small_kernel) instead of the pipeline
+        bool small = false;
+        int small_G = 0;
+        const uint8_t* s_text0 = nullptr; const int64_t* s_off = nullptr; int64_t s_base = 0, s_bytes = 0, s_docs = 0;
+        int32_t s_max_len = 0; int32_t* s_ids = nullptr; int32_t* s_mask = nullptr; int32_t* s_nreal = nullptr; int32_t* s_arena = nullptr;
+        bool keep_words = false;
     } pend;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     // timed calls that were chained without a host sync in between: start / end of the main kernels of the last RING
@@ -202,6 +208,9 @@ int enqueue(gz_ctx* c)
     }
     const bool two = p.subs.size() > 1;
     if (two) { HIPCHK(c, hipEventRecord(c->ev_fork, s)); HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0)); }
+    if (p.small)
+        gz_launch_small(T, p.s_text0, p.s_off, p.s_base, p.s_bytes, p.s_docs, p.small_G, p.s_max_len, p.use_words, p.s_ids, p.s_mask, p.s_nreal,
+                        p.s_arena, s);
     for (size_t k = 0; k < p.subs.size(); ++k) {
         hipStream_t sk = (k & 1) ? c->stream2 : s;
         const GzAsmArgs& S = p.subs[k];
@@ -392,6 +401,28 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
         // raw token counts live in a private buffer: n_real is rewritten by the finalize kernel
         rc = ensure(c, c->w_status, (size_t)(n_docs + 1) * 4); if (rc) return rc;
         n_raw = (int32_t*)c->w_status.p;
+    }
+    p.keep_words = (flags & GZ_KEEP_WORDS) != 0;
+    {
+        // Small batches run in ONE launch that cuts the work by documents (gz_small.inc): dense single texts whose longest
+        // document fits a workgroup's LDS.  The host needs the document sizes for that, so only calls that bring host
+        // offsets qualify.  GZ_SMALL=0 switches the path off (tests run the golden batches both ways).
+        static const int small_on = getenv("GZ_SMALL") ? atoi(getenv("GZ_SMALL")) : 1;
+        if (small_on && h_text_off && !is_pair && dense && max_len <= GZ_SMALL_MAX_LEN && !p.keep_words && n_docs > 0 &&
+            n_docs <= (1 << 20) && text_bytes <= (2ll << 20)) {
+            int64_t maxdoc = 0;
+            for (int64_t d = 0; d < n_docs; ++d) { const int64_t b = h_text_off[d + 1] - h_text_off[d]; if (b > maxdoc) maxdoc = b; }
+            if (maxdoc <= GZ_SMALL_DOC_BYTES) {
+                int64_t G = maxdoc > 0 ? GZ_SMALL_DOC_BYTES / maxdoc : GZ_SMALL_DOCS_PER_WG;
+                if (G > GZ_SMALL_DOCS_PER_WG) G = GZ_SMALL_DOCS_PER_WG;
+                gz_ctx::TextWs& W = c->tw[0][0];
+                if ((rc = ensure(c, W.mtok, (size_t)(text_bytes + 32) * 4))) return rc;      // arena of very long words
+                p.small = true; p.small_G = (int)G;
+                p.s_text0 = text + cutA[0]; p.s_off = text_off; p.s_base = cutA[0]; p.s_bytes = text_bytes; p.s_docs = n_docs;
+                p.s_max_len = max_len; p.s_ids = input_ids; p.s_mask = attention_mask; p.s_nreal = n_real; p.s_arena = (int32_t*)W.mtok.p;
+                nsub = 0;
+            }
+        }
     }
     p.subs.resize((size_t)nsub);
     for (int k = 0; k < nsub; ++k) {
@@ -963,6 +994,7 @@ int gz_word_token_counts(gz_ctx* c, int which_text, int32_t* counts, int64_t cap
     HIPCHK(c, hipSetDevice(c->device));
     if (c->pend.active) { int rc = sync_locked(c); if (rc) return rc; }
     const std::vector<GzAsmArgs>& subs = c->pend.subs;
+    if (!c->pend.keep_words) return fail(c, GZ_E_INVALID, "the last encode call was not made with GZ_KEEP_WORDS");
     if (subs.empty() || which_text >= subs[0].n_texts) return fail(c, GZ_E_INVALID, "no encode call with that text to report on");
     if (subs.size() > 2) return fail(c, GZ_E_INVALID, "word counts are kept for batches of fewer than 65536 documents only");
     int64_t wbase = 0, dbase = 0;

@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "libgenz_tokenize_hip.so")
 
 GZ_OK, GZ_E_INVALID, GZ_E_UTF8, GZ_E_HIP, GZ_E_NOTABLES = 0, -1, -2, -3, -4
 GZ_E_CAPACITY, GZ_E_LIMIT, GZ_E_NOMEM, GZ_E_RCCL, GZ_E_NODEVICE = -5, -6, -7, -8, -9
-GZ_PADDING, GZ_TRUNCATION, GZ_MAX_LEN_NONE, GZ_TIMING, GZ_NO_WORD_TABLE = 0x1, 0x2, 0x4, 0x100, 0x200
+GZ_PADDING, GZ_TRUNCATION, GZ_MAX_LEN_NONE, GZ_TIMING, GZ_NO_WORD_TABLE, GZ_KEEP_WORDS = 0x1, 0x2, 0x4, 0x100, 0x200, 0x400
 GZ_NONE = -1
 GZ_PP_HTML, GZ_PP_UNICODE, GZ_PP_PUNCT, GZ_PP_EMOJI, GZ_PP_URL = 1, 2, 3, 4, 5
 

@@ -160,19 +160,19 @@ class Tokenize(object):
         return "@@ ".join(strs)[:-4]
 
     # ---- encode / decode -------------------------------------------------------------------------------------
-    def _run(self, texts, pairs, max_len, padding, truncation, word_table=True):
+    def _run(self, texts, pairs, max_len, padding, truncation, word_table=True, keep_words=False):
         self._sync_tables()
         tb, to = _pack(texts)
         pb = po = None
         if pairs is not None:
             pb, po = _pack(pairs)
         return self._ctx.encode(tb, to, pb, po, max_len, bool(padding), bool(truncation),
-                                0 if word_table else _native.GZ_NO_WORD_TABLE)
+                                (0 if word_table else _native.GZ_NO_WORD_TABLE) | (_native.GZ_KEEP_WORDS if keep_words else 0))
 
     def encode(self, sentence, return_offset) -> List[int]:
         """tokenize.py:126-135."""
         _require_str(sentence)
-        r = self._run([sentence], None, None, False, False)
+        r = self._run([sentence], None, None, False, False, keep_words=bool(return_offset))
         ids = r["input_ids"].tolist()
         if return_offset:
             return ids, self._offsets(0, len(sentence.encode("utf-8", "surrogatepass")))
@@ -256,7 +256,7 @@ class Tokenize(object):
             _require_str(pair_text)
         if max_len is not None and not isinstance(max_len, (int, np.integer)):
             raise TypeError("max_len must be an int or None")
-        r = self._run([text], None if pair_text is None else [pair_text], max_len, padding, truncation)
+        r = self._run([text], None if pair_text is None else [pair_text], max_len, padding, truncation, keep_words=bool(return_offset))
         if pair_text is not None and int(r["status"][0]) != 0:
             raise ValueError("None is not in list")                 # tokenize.py:157-160, rule P3
         result = {}

@@ -45,6 +45,8 @@ extern "C" {
 #define GZ_MAX_LEN_NONE  0x4u   /* max_len=None (the max_len argument is ignored) */
 #define GZ_TIMING        0x100u /* record HIP events around the kernels (gz_timing) */
 #define GZ_NO_WORD_TABLE 0x200u /* do not consult the whole-word table: every word runs the merge loop (same results) */
+#define GZ_KEEP_WORDS    0x400u /* keep the per-word records of this call for gz_word_token_counts (return_offset=True): small
+                                   batches otherwise run in ONE fused launch that keeps nothing per word */
 
 #define GZ_NONE (-1)            /* Python None in sequence_id / token_type_ids */
 
@@ -131,7 +133,8 @@ int  gz_sync(gz_ctx *ctx);
 /* Token count of every word of the LAST encode call (for `return_offset=True`, tokenize.py:105,111-117,225-244):
  * which_text 0 = text, 1 = pair text.  counts[w] = pieces of word w (words of all documents, in order),
  * doc_first[d] = index of document d's first word (n_docs+1 entries).  Returns GZ_E_CAPACITY (and *n_words)
- * when the batch has more than `capacity` words.  Valid until the next encode call on the context. */
+ * when the batch has more than `capacity` words.  Valid until the next encode call on the context.  The encode call
+ * must have been made with GZ_KEEP_WORDS (GZ_E_INVALID otherwise). */
 int  gz_word_token_counts(gz_ctx *ctx, int which_text, int32_t *counts, int64_t capacity,
                           int64_t *doc_first, int64_t *n_words);
 

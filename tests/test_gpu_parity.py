@@ -270,6 +270,53 @@ def test_fused_split_kernel_path():
     assert " passed" in r.stdout and "failed" not in r.stdout
 
 
+def test_big_pipeline_on_small_inputs():
+    """Small dense single-text batches run in ONE fused launch (gz_small_kernel); GZ_SMALL=0 sends them through the
+    kernel pipeline instead.  The golden vectors and the small-input comparisons of this file run again that way in a
+    child process, so that both forms stay pinned to the reference on the hostile small cases."""
+    import subprocess
+    import sys
+    env = dict(os.environ, GZ_SMALL="0")
+    here = os.path.abspath(__file__)
+    r = subprocess.run([sys.executable, "-m", "pytest", here, "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider", "-k",
+                        "g1_cases or g3_random or g4_loader or cfg2_10k or cfg3_20k or noisy_corpus or long_and_huge or random_tables_fuzz or extreme_batch"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+def test_small_kernel_shapes(tok, oracle_tables, sampler):
+    """The one-launch path on its edge shapes, against the C oracle: documents of exactly 4 096 bytes (one per workgroup),
+    64 tiny documents per workgroup, empty documents, every max_len class (1, 2, 3, odd, 1 024), a long word, a word of
+    more than 1 024 symbols, and a batch just under / over the size limit of the path (2 MB)."""
+    import gz_oracle_c as OC
+    co = OC.COracle(open(corpus.VOCAB_PATH, "rb").read(), open(corpus.BPE_PATH, "rb").read())
+    text, offs, _ = corpus.config_corpus(3, n_docs=3000, seed=51, sampler=sampler)
+    text, offs = corpus.add_noise(text, offs, seed=8, rate=0.05)
+    raw = text.tobytes()
+    docs = [raw[offs[i]:offs[i + 1]] for i in range(len(offs) - 1)]
+    docs = [d[:4096] for d in docs]
+    docs = [d if len(d) < 4096 or (d[-1] & 0xC0) != 0x80 else d[:4093] for d in docs]           # keep the cut on a character boundary
+    docs = [d.decode("utf-8", "ignore").encode("utf-8") for d in docs]
+    big = ("kh\u00f4ng " * 700).encode("utf-8")[:4096].decode("utf-8", "ignore").encode("utf-8")
+    docs += [b"", b" ", b"a", b"", big, b"x" * 4096, ("\u1ea5" * 1300).encode("utf-8"), b"zq" * 2048, b"\n".join([b"ab"] * 1300), b""]
+    docs += [b"w%d" % i for i in range(300)]
+    o = np.zeros(len(docs) + 1, np.int64); np.cumsum([len(d) for d in docs], out=o[1:])
+    t = np.frombuffer(b"".join(docs) + b"  ", np.uint8)[:int(o[-1])]
+    assert int(o[-1]) < (2 << 20)
+    for ml in (1, 2, 3, 7, 64, 256, 1024):
+        got = tok.encode_packed(t, o, max_len=ml)
+        wi, wm, _, _, row, _, _ = co.call_packed(np.ascontiguousarray(t), o, max_len=ml)
+        k = int(row[-1])
+        assert np.array_equal(got["input_ids"].reshape(-1), wi[:k]), ml
+        assert np.array_equal(got["attention_mask"].reshape(-1), wm[:k]), ml
+        assert np.array_equal(got["n_real"], wm[:k].reshape(-1, ml).sum(1)), ml           # (no real token has the pad id here)
+    # every word through the merge loop
+    got = tok.encode_packed(t, o, max_len=48, word_table=False)
+    wi, wm, _, _, row, _, _ = co.call_packed(np.ascontiguousarray(t), o, max_len=48)
+    assert np.array_equal(got["input_ids"].reshape(-1), wi[:int(row[-1])])
+
+
 def test_device_entry_points_take_absolute_offsets(tok, oracle_tables, sampler):
     """gz_preprocess_batch_device and gz_decode_batch_device read their input like gz_encode_batch_device: offsets are
     absolute from the base pointer, the first one need not be 0."""
