@@ -134,6 +134,8 @@ struct gz_ctx {
     hipEvent_t ev_in[CSR_SUBS] = {}, ev_done[CSR_SUBS] = {};
     DBuf w_csr_ids[2], w_csr_mask[2], w_csr_comp, w_csr_nreal, w_csr_off32;
     uint32_t* h_tot = nullptr;           // pinned: compact size of every sub-batch
+    uint8_t* h_stage = nullptr; size_t h_stage_cap = 0;      // pinned staging of small host calls (one copy in, one copy out)
+    DBuf w_stage;
     bool building_words = false;         // the whole-word table is being built: ignore diagnostics
     bool no_words_env = false;           // GZ_WORD_TABLE=0 in the environment
 };
@@ -200,7 +202,7 @@ int enqueue(gz_ctx* c)
     hipStream_t s = c->stream;
     const GzDeviceTables* T = (const GzDeviceTables*)c->t_struct.p;
     if (c->x_used) HIPCHK(c, hipStreamWaitEvent(s, c->ev_x, 0));    // output buffers may still be read by an exchange step
-    HIPCHK(c, hipMemsetAsync(c->w_flags.p, 0, 16, s));     // [1] capacity error, [3] a word needs the wide / long kernels
+    if (!p.small) HIPCHK(c, hipMemsetAsync(c->w_flags.p, 0, 16, s));     // [0] scan time-out, [1] capacity error, [3] a word needs the wide / long kernels
     if (p.timing) {
         hipEvent_t* slot = c->ring[c->ring_n % gz_ctx::RING];
         if (!slot[0]) { HIPCHK(c, hipEventCreate(&slot[0])); HIPCHK(c, hipEventCreate(&slot[1])); }
@@ -227,7 +229,8 @@ int enqueue(gz_ctx* c)
     if (p.timing) HIPCHK(c, hipEventRecord(c->ev[2], s));
     if (p.pair) gz_launch_pair(c->dev, p.P, s);
     if (p.timing) HIPCHK(c, hipEventRecord(c->ev[3], s));
-    HIPCHK(c, hipMemcpyAsync(c->h_flags, c->w_flags.p, 8, hipMemcpyDeviceToHost, s));
+    if (!p.small) HIPCHK(c, hipMemcpyAsync(c->h_flags, c->w_flags.p, 8, hipMemcpyDeviceToHost, s));
+    else c->h_flags[0] = c->h_flags[1] = 0;                     // (the one-launch path raises neither flag)
     HIPCHK(c, hipEventRecord(c->ev_tok[c->enc_seq & 3], s));
     c->enc_seq++;
     HIPCHK(c, hipGetLastError());
@@ -609,6 +612,8 @@ void gz_destroy(gz_ctx* c)
     for (auto& e : c->ev_in) if (e) hipEventDestroy(e);
     for (auto& e : c->ev_done) if (e) hipEventDestroy(e);
     if (c->h_tot) hipHostFree(c->h_tot);
+    if (c->h_stage) hipHostFree(c->h_stage);
+    release(c->w_stage);
     for (DBuf* b : {&c->w_csr_ids[0], &c->w_csr_ids[1], &c->w_csr_mask[0], &c->w_csr_mask[1], &c->w_csr_comp, &c->w_csr_nreal, &c->w_csr_off32}) release(*b);
     if (c->h_pick) hipHostFree(c->h_pick);
     release(c->w_pick); release(c->w_rowoff32);
@@ -778,6 +783,48 @@ static int encode_host_locked(gz_ctx* c, const uint8_t* text, const int64_t* tex
     if (n_docs == 0) { if (row_off) row_off[0] = 0; return GZ_OK; }
 
     hipStream_t s = c->stream;
+    {
+        // Small dense single-text calls (a README-sized __call__, a few thousand sentences): ONE pinned staging block in
+        // each direction -- [offsets | text] up, [input_ids | attention_mask | n_real] down -- and one synchronisation,
+        // instead of two copies up, three blocking copies down and two synchronisations.
+        const int64_t tbs = text_off[n_docs] - text_off[0];
+        const size_t in_b = (size_t)(n_docs + 1) * 8 + (size_t)tbs + 64;
+        const size_t out_b = dense ? ((size_t)n_docs * (size_t)max_len * 2 + (size_t)n_docs) * 4 : 0;
+        if (!is_pair && dense && in_b + out_b <= ((size_t)1 << 20)) {
+            int rc0;
+            if (c->pend.active && (rc0 = sync_locked(c))) return rc0;
+            const size_t need = in_b + out_b + 64;
+            if (need > c->h_stage_cap) {
+                if (c->h_stage) hipHostFree(c->h_stage);
+                c->h_stage = nullptr; c->h_stage_cap = 0;
+                const size_t want = need < ((size_t)1 << 16) ? ((size_t)1 << 16) : need * 2;
+                if (hipHostMalloc((void**)&c->h_stage, want, hipHostMallocDefault) != hipSuccess) return fail(c, GZ_E_NOMEM, "pinned staging");
+                c->h_stage_cap = want;
+            }
+            if ((rc0 = ensure(c, c->w_stage, need))) return rc0;
+            const size_t off_b = (size_t)(n_docs + 1) * 8;
+            std::memcpy(c->h_stage, text_off, off_b);
+            if (tbs) std::memcpy(c->h_stage + off_b, text + text_off[0], (size_t)tbs);
+            HIPCHK(c, hipMemcpyAsync(c->w_stage.p, c->h_stage, off_b + (size_t)tbs, hipMemcpyHostToDevice, s));
+            const size_t out_at = (in_b + 15) & ~(size_t)15;
+            int32_t* d_ids = (int32_t*)((uint8_t*)c->w_stage.p + out_at);
+            int32_t* d_mask = d_ids + n_docs * (int64_t)max_len;
+            int32_t* d_nreal = d_mask + n_docs * (int64_t)max_len;
+            const uint8_t* d_text = (const uint8_t*)c->w_stage.p + off_b - text_off[0];
+            rc0 = encode_device_locked(c, d_text, (const int64_t*)c->w_stage.p, nullptr, nullptr, n_docs, max_len, flags, n_docs * (int64_t)max_len,
+                                       d_ids, d_mask, nullptr, nullptr, nullptr, nullptr, d_nreal, nullptr, text_off, nullptr);
+            if (rc0) return rc0;
+            HIPCHK(c, hipMemcpyAsync(c->h_stage + out_at, d_ids, out_b, hipMemcpyDeviceToHost, s));
+            if ((rc0 = sync_locked(c))) return rc0;
+            const size_t cells = (size_t)n_docs * (size_t)max_len * 4;
+            std::memcpy(input_ids, c->h_stage + out_at, cells);
+            std::memcpy(attention_mask, c->h_stage + out_at + cells, cells);
+            if (n_real) std::memcpy(n_real, c->h_stage + out_at + 2 * cells, (size_t)n_docs * 4);
+            if (row_off) for (int64_t i = 0; i <= n_docs; ++i) row_off[i] = i * (int64_t)max_len;
+            if (status) std::memset(status, 0, (size_t)n_docs * 4);
+            return GZ_OK;
+        }
+    }
     const int64_t tb = text_off[n_docs] - text_off[0];
     const int64_t pb = is_pair ? pair_off[n_docs] - pair_off[0] : 0;
     int rc;

@@ -1,0 +1,20 @@
+import os, sys, time
+ROOT = os.getcwd()
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "genz-tokenize_amd"))
+import numpy as np, corpus
+from genz_tokenize import Tokenize, _native
+tok = Tokenize(); tok._sync_tables(); ctx = tok._ctx
+t2, o2, L2 = corpus.config_corpus(2)
+t2 = np.ascontiguousarray(t2); o2 = np.ascontiguousarray(o2, dtype=np.int64)
+n = len(o2) - 1
+d_t = ctx.alloc(len(t2) + 64); ctx.h2d(d_t, t2)
+d_o = ctx.alloc(8 * (n + 1)); ctx.h2d(d_o, o2)
+d_i = ctx.alloc(4 * n * L2); d_m = ctx.alloc(4 * n * L2); d_r = ctx.alloc(4 * n)
+flags = _native.GZ_PADDING | _native.GZ_TRUNCATION | _native.GZ_TIMING
+res = []
+for k in range(23):
+    a = time.perf_counter()
+    ctx.encode_device(d_t, d_o, 0, 0, n, L2, flags, n * L2, d_i, d_m, d_n_real=d_r, h_text_off=o2)
+    ctx.sync()
+    res.append(((time.perf_counter() - a) * 1e3, ctx.timing()[0]))
+print("configs[1] %s: wall ms median %.4f  kernels ms median %.4f" % (os.environ.get("GZ_SMALL", "1"), np.median([x for x, _ in res[3:]]), np.median([y for _, y in res[3:]])))
