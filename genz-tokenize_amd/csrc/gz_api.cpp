@@ -87,9 +87,10 @@ struct gz_ctx {
         std::vector<GzAsmArgs> subs;   // sub-batches of the call (contiguous document ranges)
         int use_words = 0;             // bit 0: whole-word table; bits 8..: timing diagnostics (GZ_ABLATE)
         // small batches: ONE fused launch (gz_small_kernel) instead of the pipeline
-        bool small = false;
+        bool small = false, s_dense = true;
         int small_G = 0;
-        const uint8_t* s_text0 = nullptr; const int64_t* s_off = nullptr; int64_t s_base = 0, s_bytes = 0, s_docs = 0;
+        const uint8_t* s_text0 = nullptr; const int64_t* s_off = nullptr; int64_t s_base = 0, s_docs = 0;
+        const uint8_t* s_pair0 = nullptr; const int64_t* s_poff = nullptr; int64_t s_pbase = 0;
         int32_t s_max_len = 0; int32_t* s_ids = nullptr; int32_t* s_mask = nullptr; int32_t* s_nreal = nullptr; int32_t* s_arena = nullptr;
         bool keep_words = false;
     } pend;
@@ -202,7 +203,8 @@ int enqueue(gz_ctx* c)
     hipStream_t s = c->stream;
     const GzDeviceTables* T = (const GzDeviceTables*)c->t_struct.p;
     if (c->x_used) HIPCHK(c, hipStreamWaitEvent(s, c->ev_x, 0));    // output buffers may still be read by an exchange step
-    if (!p.small) HIPCHK(c, hipMemsetAsync(c->w_flags.p, 0, 16, s));     // [0] scan time-out, [1] capacity error, [3] a word needs the wide / long kernels
+    const bool no_flags = p.small && !p.ragged;                 // (a dense one-launch call raises no flag)
+    if (!no_flags) HIPCHK(c, hipMemsetAsync(c->w_flags.p, 0, 16, s));     // [0] scan time-out, [1] capacity error, [3] a word needs the wide / long kernels
     if (p.timing) {
         hipEvent_t* slot = c->ring[c->ring_n % gz_ctx::RING];
         if (!slot[0]) { HIPCHK(c, hipEventCreate(&slot[0])); HIPCHK(c, hipEventCreate(&slot[1])); }
@@ -211,8 +213,8 @@ int enqueue(gz_ctx* c)
     const bool two = p.subs.size() > 1;
     if (two) { HIPCHK(c, hipEventRecord(c->ev_fork, s)); HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0)); }
     if (p.small)
-        gz_launch_small(T, p.s_text0, p.s_off, p.s_base, p.s_bytes, p.s_docs, p.small_G, p.s_max_len, p.use_words, p.s_ids, p.s_mask, p.s_nreal,
-                        p.s_arena, s);
+        gz_launch_small(T, p.s_text0, p.s_off, p.s_base, p.s_pair0, p.s_poff, p.s_pbase, p.s_docs, p.small_G, p.s_dense ? 1 : 0, p.s_max_len,
+                        p.use_words, p.s_ids, p.s_mask, p.s_nreal, p.s_arena, s);
     for (size_t k = 0; k < p.subs.size(); ++k) {
         hipStream_t sk = (k & 1) ? c->stream2 : s;
         const GzAsmArgs& S = p.subs[k];
@@ -229,8 +231,8 @@ int enqueue(gz_ctx* c)
     if (p.timing) HIPCHK(c, hipEventRecord(c->ev[2], s));
     if (p.pair) gz_launch_pair(c->dev, p.P, s);
     if (p.timing) HIPCHK(c, hipEventRecord(c->ev[3], s));
-    if (!p.small) HIPCHK(c, hipMemcpyAsync(c->h_flags, c->w_flags.p, 8, hipMemcpyDeviceToHost, s));
-    else c->h_flags[0] = c->h_flags[1] = 0;                     // (the one-launch path raises neither flag)
+    if (!no_flags) HIPCHK(c, hipMemcpyAsync(c->h_flags, c->w_flags.p, 8, hipMemcpyDeviceToHost, s));
+    else c->h_flags[0] = c->h_flags[1] = 0;
     HIPCHK(c, hipEventRecord(c->ev_tok[c->enc_seq & 3], s));
     c->enc_seq++;
     HIPCHK(c, hipGetLastError());
@@ -407,22 +409,27 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
     }
     p.keep_words = (flags & GZ_KEEP_WORDS) != 0;
     {
-        // Small batches run in ONE launch that cuts the work by documents (gz_small.inc): dense single texts whose longest
-        // document fits a workgroup's LDS.  The host needs the document sizes for that, so only calls that bring host
-        // offsets qualify.  GZ_SMALL=0 switches the path off (tests run the golden batches both ways).
+        // Small batches run in ONE launch that cuts the work by documents (gz_small.inc): single texts or pairs whose
+        // longest document fits a workgroup's LDS (ragged layouts: the unpadded rows go to the raw area, finalize follows as in
+        // the big path).  The host needs the document sizes for that, so only calls that bring host offsets qualify.  GZ_SMALL=0 switches the path off (tests run the golden batches both ways).
         static const int small_on = getenv("GZ_SMALL") ? atoi(getenv("GZ_SMALL")) : 1;
-        if (small_on && h_text_off && !is_pair && dense && max_len <= GZ_SMALL_MAX_LEN && !p.keep_words && n_docs > 0 &&
-            n_docs <= (1 << 20) && text_bytes <= (2ll << 20)) {
-            int64_t maxdoc = 0;
-            for (int64_t d = 0; d < n_docs; ++d) { const int64_t b = h_text_off[d + 1] - h_text_off[d]; if (b > maxdoc) maxdoc = b; }
+        if (small_on && h_text_off && !p.keep_words && n_docs > 0 && n_docs <= (1 << 20) && text_bytes + pair_bytes <= (2ll << 20)) {
+            int64_t maxdoc = 0, maxpair = 0;
+            for (int64_t d = 0; d < n_docs; ++d) {
+                const int64_t b = h_text_off[d + 1] - h_text_off[d]; if (b > maxdoc) maxdoc = b;
+                if (is_pair) { const int64_t b2 = h_pair_off[d + 1] - h_pair_off[d]; if (b2 > maxpair) maxpair = b2; }
+            }
+            maxdoc += maxpair;                                   // a group of G documents holds at most G * (longest A + longest B) bytes
             if (maxdoc <= GZ_SMALL_DOC_BYTES) {
                 int64_t G = maxdoc > 0 ? GZ_SMALL_DOC_BYTES / maxdoc : GZ_SMALL_DOCS_PER_WG;
                 if (G > GZ_SMALL_DOCS_PER_WG) G = GZ_SMALL_DOCS_PER_WG;
                 gz_ctx::TextWs& W = c->tw[0][0];
-                if ((rc = ensure(c, W.mtok, (size_t)(text_bytes + 32) * 4))) return rc;      // arena of very long words
+                if ((rc = ensure(c, W.mtok, (size_t)(text_bytes + pair_bytes + 32) * 4))) return rc;      // arena of very long words
                 p.small = true; p.small_G = (int)G;
-                p.s_text0 = text + cutA[0]; p.s_off = text_off; p.s_base = cutA[0]; p.s_bytes = text_bytes; p.s_docs = n_docs;
-                p.s_max_len = max_len; p.s_ids = input_ids; p.s_mask = attention_mask; p.s_nreal = n_real; p.s_arena = (int32_t*)W.mtok.p;
+                p.s_text0 = text + cutA[0]; p.s_off = text_off; p.s_base = cutA[0]; p.s_docs = n_docs;
+                if (is_pair) { p.s_pair0 = pair + cutB[0]; p.s_poff = pair_off; p.s_pbase = cutB[0]; }
+                p.s_dense = dense; p.s_max_len = max_len; p.s_arena = (int32_t*)W.mtok.p;
+                p.s_ids = dense ? input_ids : raw; p.s_mask = dense ? attention_mask : raw; p.s_nreal = dense ? n_real : n_raw;
                 nsub = 0;
             }
         }
@@ -784,16 +791,25 @@ static int encode_host_locked(gz_ctx* c, const uint8_t* text, const int64_t* tex
 
     hipStream_t s = c->stream;
     {
-        // Small dense single-text calls (a README-sized __call__, a few thousand sentences): ONE pinned staging block in
-        // each direction -- [offsets | text] up, [input_ids | attention_mask | n_real] down -- and one synchronisation,
-        // instead of two copies up, three blocking copies down and two synchronisations.
-        const int64_t tbs = text_off[n_docs] - text_off[0];
-        const size_t in_b = (size_t)(n_docs + 1) * 8 + (size_t)tbs + 64;
-        const size_t out_b = dense ? ((size_t)n_docs * (size_t)max_len * 2 + (size_t)n_docs) * 4 : 0;
-        if (!is_pair && dense && in_b + out_b <= ((size_t)1 << 20)) {
+        // Small calls (a README-sized __call__, a few thousand sentences): ONE pinned staging block in each direction --
+        // [text_off | text | pair_off | pair] up, [row_off | input_ids | attention_mask | token_type_ids | sequence_id |
+        // n_real | pair_len | status] down -- and one synchronisation, instead of up to four copies up, nine blocking
+        // copies down and two synchronisations.  Ragged outputs come down at their bound and are cut on the host.
+        auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
+        const int64_t tbs = text_off[n_docs] - text_off[0], pbs = is_pair ? pair_off[n_docs] - pair_off[0] : 0;
+        const size_t off_b = (size_t)(n_docs + 1) * 8;
+        const size_t in_text = up16(off_b), in_poff = up16(in_text + (size_t)tbs + 16), in_pair = up16(in_poff + (is_pair ? off_b : 0));
+        const size_t in_b = up16(in_pair + (size_t)pbs + 16);
+        int64_t E = dense ? n_docs * (int64_t)max_len : tbs + pbs + (is_pair ? 4 : 2) * n_docs;
+        if (!dense && S.pad_mode && max_len > 0) E += n_docs * (int64_t)max_len;
+        const size_t cells = up16((size_t)E * 4 + 16);
+        const size_t o_row = in_b, o_ids = up16(o_row + off_b), o_mask = o_ids + cells, o_tt = o_mask + cells,
+                     o_seq = o_tt + (is_pair ? cells : 0), o_nreal = o_seq + (is_pair ? cells : 0), o_plen = up16(o_nreal + (size_t)n_docs * 4),
+                     o_status = up16(o_plen + (is_pair ? (size_t)n_docs * 8 : 0)), o_end = up16(o_status + (is_pair ? (size_t)n_docs * 4 : 0));
+        if (o_end <= ((size_t)1 << 20)) {
             int rc0;
             if (c->pend.active && (rc0 = sync_locked(c))) return rc0;
-            const size_t need = in_b + out_b + 64;
+            const size_t need = o_end + 64;
             if (need > c->h_stage_cap) {
                 if (c->h_stage) hipHostFree(c->h_stage);
                 c->h_stage = nullptr; c->h_stage_cap = 0;
@@ -802,26 +818,42 @@ static int encode_host_locked(gz_ctx* c, const uint8_t* text, const int64_t* tex
                 c->h_stage_cap = want;
             }
             if ((rc0 = ensure(c, c->w_stage, need))) return rc0;
-            const size_t off_b = (size_t)(n_docs + 1) * 8;
-            std::memcpy(c->h_stage, text_off, off_b);
-            if (tbs) std::memcpy(c->h_stage + off_b, text + text_off[0], (size_t)tbs);
-            HIPCHK(c, hipMemcpyAsync(c->w_stage.p, c->h_stage, off_b + (size_t)tbs, hipMemcpyHostToDevice, s));
-            const size_t out_at = (in_b + 15) & ~(size_t)15;
-            int32_t* d_ids = (int32_t*)((uint8_t*)c->w_stage.p + out_at);
-            int32_t* d_mask = d_ids + n_docs * (int64_t)max_len;
-            int32_t* d_nreal = d_mask + n_docs * (int64_t)max_len;
-            const uint8_t* d_text = (const uint8_t*)c->w_stage.p + off_b - text_off[0];
-            rc0 = encode_device_locked(c, d_text, (const int64_t*)c->w_stage.p, nullptr, nullptr, n_docs, max_len, flags, n_docs * (int64_t)max_len,
-                                       d_ids, d_mask, nullptr, nullptr, nullptr, nullptr, d_nreal, nullptr, text_off, nullptr);
+            uint8_t* H = c->h_stage;
+            uint8_t* D = (uint8_t*)c->w_stage.p;
+            std::memcpy(H, text_off, off_b);
+            if (tbs) std::memcpy(H + in_text, text + text_off[0], (size_t)tbs);
+            if (is_pair) {
+                std::memcpy(H + in_poff, pair_off, off_b);
+                if (pbs) std::memcpy(H + in_pair, pair + pair_off[0], (size_t)pbs);
+            }
+            HIPCHK(c, hipMemcpyAsync(D, H, in_b, hipMemcpyHostToDevice, s));
+            rc0 = encode_device_locked(c, D + in_text - text_off[0], (const int64_t*)D, is_pair ? D + in_pair - pair_off[0] : nullptr,
+                                       is_pair ? (const int64_t*)(D + in_poff) : nullptr, n_docs, max_len, flags, E, (int32_t*)(D + o_ids),
+                                       (int32_t*)(D + o_mask), is_pair ? (int32_t*)(D + o_tt) : nullptr, is_pair ? (int32_t*)(D + o_seq) : nullptr,
+                                       (int64_t*)(D + o_row), is_pair ? (int32_t*)(D + o_plen) : nullptr, (int32_t*)(D + o_nreal),
+                                       is_pair ? (int32_t*)(D + o_status) : nullptr, text_off, pair_off);
             if (rc0) return rc0;
-            HIPCHK(c, hipMemcpyAsync(c->h_stage + out_at, d_ids, out_b, hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipMemcpyAsync(H + o_row, D + o_row, o_end - o_row, hipMemcpyDeviceToHost, s));
             if ((rc0 = sync_locked(c))) return rc0;
-            const size_t cells = (size_t)n_docs * (size_t)max_len * 4;
-            std::memcpy(input_ids, c->h_stage + out_at, cells);
-            std::memcpy(attention_mask, c->h_stage + out_at + cells, cells);
-            if (n_real) std::memcpy(n_real, c->h_stage + out_at + 2 * cells, (size_t)n_docs * 4);
-            if (row_off) for (int64_t i = 0; i <= n_docs; ++i) row_off[i] = i * (int64_t)max_len;
-            if (status) std::memset(status, 0, (size_t)n_docs * 4);
+            int64_t total = n_docs * (int64_t)max_len;
+            if (!dense) {
+                std::memcpy(row_off, H + o_row, off_b);
+                total = row_off[n_docs];
+                if (total > capacity) return fail(c, GZ_E_CAPACITY, "ragged output needs %lld entries, capacity is %lld", (long long)total, (long long)capacity);
+            } else if (row_off) {
+                for (int64_t i = 0; i <= n_docs; ++i) row_off[i] = i * (int64_t)max_len;
+            }
+            std::memcpy(input_ids, H + o_ids, (size_t)total * 4);
+            std::memcpy(attention_mask, H + o_mask, (size_t)total * 4);
+            if (is_pair) {
+                std::memcpy(token_type_ids, H + o_tt, (size_t)total * 4);
+                std::memcpy(sequence_id, H + o_seq, (size_t)total * 4);
+                std::memcpy(pair_len, H + o_plen, (size_t)n_docs * 8);
+                std::memcpy(status, H + o_status, (size_t)n_docs * 4);
+            } else if (status) {
+                std::memset(status, 0, (size_t)n_docs * 4);
+            }
+            if (n_real) std::memcpy(n_real, H + o_nreal, (size_t)n_docs * 4);
             return GZ_OK;
         }
     }

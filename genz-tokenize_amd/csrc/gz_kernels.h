@@ -76,11 +76,14 @@ void gz_launch_compact(const int32_t* rows, const uint32_t* off, int64_t n_rows,
 void gz_launch_expand(const void* compact, int bits, const uint32_t* off, int64_t n_rows, int32_t row_len, int32_t pad_id, int32_t* ids,
                       int32_t* mask, hipStream_t s);
 void gz_launch_assemble(const GzDeviceTables* T_dev, const GzAsmArgs& A, hipStream_t s);
-// small batches, one launch (gz_small.inc): single text, dense rows, every document <= GZ_SMALL_DOC_BYTES, G documents per
-// workgroup with G * (longest document) <= GZ_SMALL_DOC_BYTES and G <= GZ_SMALL_DOCS_PER_WG, max_len <= GZ_SMALL_MAX_LEN
-constexpr int GZ_SMALL_DOC_BYTES = 4096, GZ_SMALL_DOCS_PER_WG = 64, GZ_SMALL_MAX_LEN = 1024;
-void gz_launch_small(const GzDeviceTables* T_dev, const uint8_t* text0, const int64_t* off, int64_t base, int64_t B, int64_t n_docs, int G,
-                     int max_len, int use_words, int32_t* ids, int32_t* mask, int32_t* n_real, int32_t* arena, hipStream_t s);
+// small batches, one launch (gz_small.inc): G documents per workgroup, G <= GZ_SMALL_DOCS_PER_WG and every group of G
+// documents (A and B texts together) <= GZ_SMALL_DOC_BYTES.  poff == nullptr: single texts.  dense: rows of max_len into
+// ids / mask; else: unpadded rows into the raw area `ids` (document d at (bytes before d) + 2 d per text) and their
+// lengths into n_real.  arena: [text bytes + pair bytes + 32] words of scratch for very long words.
+constexpr int GZ_SMALL_DOC_BYTES = 4096, GZ_SMALL_DOCS_PER_WG = 64;
+void gz_launch_small(const GzDeviceTables* T_dev, const uint8_t* text0, const int64_t* off, int64_t base, const uint8_t* pair0, const int64_t* poff,
+                     int64_t pbase, int64_t n_docs, int G, int dense, int max_len, int use_words, int32_t* ids, int32_t* mask, int32_t* n_real,
+                     int32_t* arena, hipStream_t s);
 
 void gz_launch_rowscan(const GzFinalizeArgs& F, int64_t* row_len_tmp, hipStream_t s);
 void gz_launch_finalize(const GzDeviceTables& T, const GzFinalizeArgs& F, hipStream_t s);

@@ -288,7 +288,8 @@ def test_big_pipeline_on_small_inputs():
 def test_small_kernel_shapes(tok, oracle_tables, sampler):
     """The one-launch path on its edge shapes, against the C oracle: documents of exactly 4 096 bytes (one per workgroup),
     64 tiny documents per workgroup, empty documents, every max_len class (1, 2, 3, odd, 1 024), a long word, a word of
-    more than 1 024 symbols, and a batch just under / over the size limit of the path (2 MB)."""
+    more than 1 024 symbols, a batch just under the size limit of the path (2 MB); ragged layouts; and the pinned
+    staging block of small host calls with pairs."""
     import gz_oracle_c as OC
     co = OC.COracle(open(corpus.VOCAB_PATH, "rb").read(), open(corpus.BPE_PATH, "rb").read())
     text, offs, _ = corpus.config_corpus(3, n_docs=3000, seed=51, sampler=sampler)
@@ -315,6 +316,39 @@ def test_small_kernel_shapes(tok, oracle_tables, sampler):
     got = tok.encode_packed(t, o, max_len=48, word_table=False)
     wi, wm, _, _, row, _, _ = co.call_packed(np.ascontiguousarray(t), o, max_len=48)
     assert np.array_equal(got["input_ids"].reshape(-1), wi[:int(row[-1])])
+    # ragged layouts: the kernel leaves unpadded rows in the raw area, finalize cuts / pads them
+    for ml, pad, trunc in ((None, True, True), (64, False, True), (64, True, False), (64, False, False), (0, True, True), (-3, True, True)):
+        got = tok.encode_packed(t, o, max_len=ml, padding=pad, truncation=trunc)
+        wi, wm, _, _, row, _, _ = co.call_packed(np.ascontiguousarray(t), o, max_len=ml, padding=pad, truncation=trunc)
+        k = int(row[-1])
+        assert np.array_equal(got["row_off"], row), (ml, pad, trunc)
+        assert np.array_equal(got["input_ids"], wi[:k]), (ml, pad, trunc)
+        assert np.array_equal(got["attention_mask"], wm[:k]), (ml, pad, trunc)
+    # pairs: the one-launch kernel with two segments per document, through the pinned staging block of small host calls
+    # (<= 1 MB in + out) and through the ordinary copies (the whole batch as A, itself shifted by 7 documents as B)
+    def part(lo, hi):
+        return np.ascontiguousarray(t[int(o[lo]):int(o[hi])]), np.ascontiguousarray(o[lo:hi + 1] - o[lo])
+    nd = len(docs)
+    ta2, oa2, _ = corpus.config_corpus(2, n_docs=2000, seed=52, sampler=sampler)
+    tb2, ob2, _ = corpus.config_corpus(2, n_docs=2000, seed=53, sampler=sampler)
+    ta2, oa2 = corpus.add_noise(ta2, oa2, seed=9, rate=0.05)
+    cases = [part(0, 400) + part(400, 800),                      # long documents: the big pipeline behind the staging block
+             part(nd - 300, nd) + part(nd - 307, nd - 7),        # tiny documents, 64 pairs per workgroup, some texts empty
+             (np.ascontiguousarray(ta2), np.ascontiguousarray(oa2, dtype=np.int64), np.ascontiguousarray(tb2), np.ascontiguousarray(ob2, dtype=np.int64))]
+    for (ts, os_, pt, po), (ml, pad, trunc) in [(c, sh) for c in cases for sh in ((24, True, True), (None, True, True), (24, False, True),
+                                                                                     (24, True, False), (5, True, True), (2, True, True))]:
+        got = tok.encode_packed(ts, os_, pt, po, max_len=ml, padding=pad, truncation=trunc)
+        wi, wm, wt, wq, row, plen, st = co.call_packed(ts, os_, pt, po, max_len=ml, padding=pad, truncation=trunc)
+        k = int(row[-1])
+        ro = np.asarray(got["row_off"], np.int64)
+        assert np.array_equal(ro, row), (ml, pad, trunc)
+        assert np.array_equal(np.asarray(got["input_ids"]).reshape(-1), wi[:k]), (ml, pad, trunc)
+        assert np.array_equal(np.asarray(got["attention_mask"]).reshape(-1), wm[:k]), (ml, pad, trunc)
+        assert np.array_equal(got["status"], st), (ml, pad, trunc)
+        gl = np.asarray(got["pair_len"]).reshape(-1, 2)
+        assert np.array_equal(gl, plen.reshape(-1, 2)), (ml, pad, trunc)
+        assert np.array_equal(_gather(got["sequence_id"].reshape(-1), ro[:-1], gl[:, 0]), _gather(wq, row[:-1], gl[:, 0])), (ml, pad, trunc)
+        assert np.array_equal(_gather(got["token_type_ids"].reshape(-1), ro[:-1], gl[:, 1]), _gather(wt, row[:-1], gl[:, 1])), (ml, pad, trunc)
 
 
 def test_device_entry_points_take_absolute_offsets(tok, oracle_tables, sampler):

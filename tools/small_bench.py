@@ -18,3 +18,20 @@ for k in range(23):
     ctx.sync()
     res.append(((time.perf_counter() - a) * 1e3, ctx.timing()[0]))
 print("configs[1] %s: wall ms median %.4f  kernels ms median %.4f" % (os.environ.get("GZ_SMALL", "1"), np.median([x for x, _ in res[3:]]), np.median([y for _, y in res[3:]])))
+
+
+def per_call(fn, reps=2000):
+    for _ in range(50):
+        fn()
+    a = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    return (time.perf_counter() - a) / reps * 1e6
+
+
+s1, s2 = "sinh_viên công_nghệ", "hello"
+print("single __call__ (text, max_len=10):        %.1f us" % per_call(lambda: tok(s1, max_len=10)))
+print("single __call__ (text), ragged:            %.1f us" % per_call(lambda: tok(s1)))
+print("encode(text):                              %.1f us" % per_call(lambda: tok.encode(s1, False)))
+print("README pair __call__ (a, b, max_len=10):   %.1f us" % per_call(lambda: tok(s1, s2, max_len=10)))
+print("pair __call__ (a, b), ragged:              %.1f us" % per_call(lambda: tok(s1, s2)))
