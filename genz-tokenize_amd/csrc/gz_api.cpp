@@ -423,6 +423,11 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
             if (maxdoc <= GZ_SMALL_DOC_BYTES) {
                 int64_t G = maxdoc > 0 ? GZ_SMALL_DOC_BYTES / maxdoc : GZ_SMALL_DOCS_PER_WG;
                 if (G > GZ_SMALL_DOCS_PER_WG) G = GZ_SMALL_DOCS_PER_WG;
+                // a batch this small cannot fill the chip with full groups: more, smaller workgroups (each phase of a workgroup
+                // is a dependent chain, so the call's time is the time of ONE workgroup)
+                static const int64_t wg_target = getenv("GZ_SMALL_WGS") ? atoi(getenv("GZ_SMALL_WGS")) : 768;
+                const int64_t by_chip = (n_docs + wg_target - 1) / wg_target;
+                if (G > by_chip) G = by_chip;
                 gz_ctx::TextWs& W = c->tw[0][0];
                 if ((rc = ensure(c, W.mtok, (size_t)(text_bytes + pair_bytes + 32) * 4))) return rc;      // arena of very long words
                 p.small = true; p.small_G = (int)G;

@@ -351,6 +351,58 @@ def test_small_kernel_shapes(tok, oracle_tables, sampler):
         assert np.array_equal(_gather(got["token_type_ids"].reshape(-1), ro[:-1], gl[:, 1]), _gather(wt, row[:-1], gl[:, 1])), (ml, pad, trunc)
 
 
+def test_small_path_random_shapes(tok, sampler):
+    """The one-launch path over 60 seeded random batches against the C oracle: 1..700 documents of random length classes
+    (empty, a few bytes, sentences, up to 4 KiB), singles and pairs, every layout (dense, ragged with and without
+    padding / truncation, max_len None / <= 0 / tiny), table on and off."""
+    import random
+    import gz_oracle_c as OC
+    co = OC.COracle(open(corpus.VOCAB_PATH, "rb").read(), open(corpus.BPE_PATH, "rb").read())
+    text, offs, _ = corpus.config_corpus(3, n_docs=1500, seed=61, sampler=sampler)
+    text, offs = corpus.add_noise(text, offs, seed=11, rate=0.06)
+    raw = text.tobytes().decode("utf-8")
+    words = raw.split(" ")
+    r = random.Random(2024)
+
+    def doc():
+        k = r.choice([0, 0, 1, 1, 2, 3, 5, 8, 13, 30, 60, 120, 400])
+        i = r.randrange(len(words) - k - 1)
+        return " ".join(words[i:i + k]).encode("utf-8")[:r.choice([4096, 4096, 2000, 700])].decode("utf-8", "ignore").encode("utf-8")
+
+    def pack(docs):
+        o = np.zeros(len(docs) + 1, np.int64); np.cumsum([len(d) for d in docs], out=o[1:])
+        return np.frombuffer(b"".join(docs) + b" " * 16, np.uint8)[:int(o[-1])].copy(), o
+
+    for trial in range(60):
+        n = r.choice([1, 1, 2, 3, 7, 64, 65, 129, 300, 700])
+        pair = r.random() < 0.5
+        a = [doc() for _ in range(n)]
+        b = [doc() for _ in range(n)] if pair else None
+        ml, pad, trunc = r.choice([(None, True, True), (16, True, True), (33, True, True), (1, True, True), (2, True, True), (4, True, True),
+                                   (256, True, True), (20, False, True), (20, True, False), (20, False, False), (0, True, True), (-2, True, True)])
+        wt = r.random() < 0.8
+        ta, oa = pack(a)
+        if pair:
+            tb, ob = pack(b)
+            got = tok.encode_packed(ta, oa, tb, ob, max_len=ml, padding=pad, truncation=trunc, word_table=wt)
+            wi, wm, wtt, wq, row, plen, st = co.call_packed(ta, oa, tb, ob, max_len=ml, padding=pad, truncation=trunc)
+        else:
+            got = tok.encode_packed(ta, oa, max_len=ml, padding=pad, truncation=trunc, word_table=wt)
+            wi, wm, wtt, wq, row, plen, st = co.call_packed(ta, oa, max_len=ml, padding=pad, truncation=trunc)
+        what = (trial, n, pair, ml, pad, trunc, wt)
+        k = int(row[-1])
+        ro = np.asarray(got["row_off"], np.int64)
+        assert np.array_equal(ro, row), what
+        assert np.array_equal(np.asarray(got["input_ids"]).reshape(-1)[:k], wi[:k]), what
+        assert np.array_equal(np.asarray(got["attention_mask"]).reshape(-1)[:k], wm[:k]), what
+        if pair:
+            assert np.array_equal(got["status"], st), what
+            gl = np.asarray(got["pair_len"]).reshape(-1, 2)
+            assert np.array_equal(gl, plen.reshape(-1, 2)), what
+            assert np.array_equal(_gather(np.asarray(got["sequence_id"]).reshape(-1), ro[:-1], gl[:, 0]), _gather(wq, row[:-1], gl[:, 0])), what
+            assert np.array_equal(_gather(np.asarray(got["token_type_ids"]).reshape(-1), ro[:-1], gl[:, 1]), _gather(wtt, row[:-1], gl[:, 1])), what
+
+
 def test_device_entry_points_take_absolute_offsets(tok, oracle_tables, sampler):
     """gz_preprocess_batch_device and gz_decode_batch_device read their input like gz_encode_batch_device: offsets are
     absolute from the base pointer, the first one need not be 0."""

@@ -19,6 +19,9 @@ for k in range(23):
     res.append(((time.perf_counter() - a) * 1e3, ctx.timing()[0]))
 print("configs[1] %s: wall ms median %.4f  kernels ms median %.4f" % (os.environ.get("GZ_SMALL", "1"), np.median([x for x, _ in res[3:]]), np.median([y for _, y in res[3:]])))
 
+if os.environ.get("SMALL_ONLY"):
+    sys.exit(0)
+
 
 def per_call(fn, reps=2000):
     for _ in range(50):
