@@ -517,6 +517,7 @@ def main():
         in_b = shards[0]["in_bytes"] if m == 1 else float(np.mean([sh["in_bytes"] for sh in shards]))
         algo = _algo_bytes(in_b, n, L)
         achieved = algo / (k_ms * 1e-3) / 1e9
+        shard_traffic = _pmc_traffic("r02_pmc_traffic_shard.json")
         out = {
             "metric": "UTF-8 MB/s tokenized (Tokenize.__call__ hot path: split + BPE + vocab lookup + pad/trunc + mask)",
             "value": round(total_bytes * args.steps / elapsed / 1e6, 2),
@@ -541,9 +542,11 @@ def main():
                          "kernel": "one launch of the pipeline = one shard of %d documents, on one stream: %s" % (n, PIPELINE),
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
-                         "traffic": None,
-                         "traffic_note": "PMC traffic is collected on the configs[2] roofline run (see configs_2_roofline_run and profiles/); "
-                                         "null here: no counter pass at this commit covers a 1.25 M-document launch",
+                         "traffic": shard_traffic["bytes_per_step"] if shard_traffic else None,
+                         "traffic_note": ("profiles/r02_pmc_traffic_shard.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over one "
+                                          "launch on shard 0 (1.25 M documents), same kernel sources (sha %s); reads of 16-B streams are "
+                                          "half-counted on gfx950, not corrected" % kernel_source_sha16()) if shard_traffic else
+                                         "null: profiles/r02_pmc_traffic_shard.json is absent or was taken on other kernel sources",
                          "algorithmic_bytes_per_launch": int(algo),
                          "kernel_ms_avg": round(k_ms, 4), "launches_timed": len(kernel_ms),
                          "timed_with": "hipEvents on the library's stream around each launch of the pipeline, inside the timed region"},
@@ -554,6 +557,17 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def _pmc_traffic(name):
+    """A committed PMC traffic summary, or None unless it was taken on this pipeline and these kernel sources."""
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", name)))
+        if tj.get("pipeline") == PIPELINE and tj.get("source_sha16") == kernel_source_sha16():
+            return tj
+    except Exception:  # noqa: BLE001
+        pass
+    return None
 
 
 def secondary(ctx, tok, flags, args, cfg2):
@@ -577,13 +591,7 @@ def secondary(ctx, tok, flags, args, cfg2):
     n_tok = int(mask.sum(dtype=np.int64))
     del ids, mask
     algo = _algo_bytes(R.in_bytes, R.n, L)
-    traffic = None
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
-        if tj.get("pipeline") == PIPELINE and tj.get("source_sha16") == kernel_source_sha16():
-            traffic = tj
-    except Exception:  # noqa: BLE001
-        pass
+    traffic = _pmc_traffic("r02_pmc_traffic.json")
     # (ii) device end-to-end: host buffers in, host buffers out (PCIe both ways).  The library's host path for batches is
     # gz_encode_batch_csr: sub-batches, text H2D / kernels / D2H on three streams, and only the rows' real entries
     # (16-bit) + 4 bytes per document come back; the buffers are pinned (gz_host_alloc), as SURVEY.md 8(d) (ii) says.
@@ -703,7 +711,8 @@ def secondary(ctx, tok, flags, args, cfg2):
     if e2:
         sys.exit("bench: " + e2)
     wall = float(np.median([a for a, _ in ms3[3:]])); kern = float(np.median([b for _, b in ms3[3:]]))
-    out["configs_1_small_batch"] = {"workload": "BASELINE configs[1]: %d short sentences (%.2f MB), max_len=%d" % (R2.n, R2.in_bytes / 1e6, L2),
+    out["configs_1_small_batch"] = {"workload": "BASELINE configs[1]: %d short sentences (%.2f MB), max_len=%d; one launch (gz_small_kernel)"
+                                                % (R2.n, R2.in_bytes / 1e6, L2),
                                     "ms_per_step_wall": round(wall, 4), "kernels_ms": round(kern, 4),
                                     "MB_per_s": round(R2.in_bytes / wall / 1e3, 1), "verified": "reference sha256 (cfg2_10k): match"}
     R2.free()

@@ -22,6 +22,9 @@ cd $R
 # (3) HBM traffic, one counter per pass
 tools/pmc.sh fin_$tag 1000000 "FETCH_SIZE" "WRITE_SIZE" || exit 1
 python3 tools/pmc_traffic.py gpurun_out/pmc_fin_${tag}_1 gpurun_out/pmc_fin_${tag}_2 $O/pmc_traffic.json "$(python3 -c 'import bench; print(bench.PIPELINE)')"
+# (3b) the same for one shard of the headline job (BASELINE configs[3]: 1.25 M documents, seed 100 = shard 0)
+SEED=100 tools/pmc.sh finS_$tag 1250000 "FETCH_SIZE" "WRITE_SIZE" || exit 1
+python3 tools/pmc_traffic.py gpurun_out/pmc_finS_${tag}_1 gpurun_out/pmc_finS_${tag}_2 $O/pmc_traffic_shard.json "$(python3 -c 'import bench; print(bench.PIPELINE)')" "" "BASELINE configs[3], shard 0: 1.25 M documents (seed 100), 358 MB, max_len 256 (SEED=100 tools/prof_run.py 1250000 2)"
 echo "(3) done" >> $O/progress.txt
 # (4) the default bench line
 timeout -k 10 700 python3 bench.py > $O/bench.json.log 2>$O/bench.err || { tail -5 $O/bench.err; exit 1; }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """HBM traffic per kernel and per launch of the pipeline from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; KiB).
-usage: pmc_traffic.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <out.json> [pipeline string] [note]
+usage: pmc_traffic.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <out.json> [pipeline string] [note] [workload]
 
 The LAST launch of the pipeline in each pass is summed: every gz_* dispatch from the last gz_brk_kernel on (the
 pipeline's first kernel), so kernels that run more than once per launch count as often as they run."""
@@ -31,7 +31,7 @@ def last_launch(d, counter):
 
 fetch, write = last_launch(sys.argv[1], 'FETCH_SIZE'), last_launch(sys.argv[2], 'WRITE_SIZE')
 total = (sum(fetch.values()) + sum(write.values())) * 1024
-out = {"workload": "BASELINE configs[2]: 1 M documents, 287 MB, max_len 256 (tools/prof_run.py 1000000 2)",
+out = {"workload": sys.argv[6] if len(sys.argv) > 6 else "BASELINE configs[2]: 1 M documents, 287 MB, max_len 256 (tools/prof_run.py 1000000 2)",
        "pipeline": sys.argv[4] if len(sys.argv) > 4 else None,
        "source_sha16": __import__("bench").kernel_source_sha16(),      # bench.py quotes this file only for the same kernel sources
        "per_kernel_KiB": {"FETCH_SIZE": fetch, "WRITE_SIZE": write}, "bytes_per_step": int(total),

@@ -14,7 +14,8 @@ n_docs = int(sys.argv[1]) if len(sys.argv) > 1 else 200_000
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 cfg = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 tok = Tokenize(); tok._sync_tables(); ctx = tok._ctx
-text, offs, L = corpus.config_corpus(cfg, n_docs=n_docs)
+seed = int(os.environ["SEED"]) if os.environ.get("SEED") else None       # (SEED=100, 1250000 documents: shard 0 of BASELINE configs[3])
+text, offs, L = corpus.config_corpus(cfg, n_docs=n_docs, seed=seed)
 n = len(offs) - 1
 d_text = ctx.alloc(len(text) + 64); ctx.h2d(d_text, text)
 d_off = ctx.alloc(8 * (n + 1)); ctx.h2d(d_off, offs)

@@ -9,10 +9,13 @@ for r in csv.DictReader(open(f)):
         name = name[5:]
     if name.startswith('gz_'):
         by[name.split('(')[0]].append((int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3)
+steps = len(by.get('gz_brk_kernel', [])) or 1        # launches of the pipeline in the trace
 tot = 0
 for k, v in by.items():
-    last = v[-3:]
-    print("%-24s n=%d last3 avg %8.1f us" % (k, len(v), sum(last) / len(last)))
-    if k not in ('gz_scan_kernel', 'gz_finalize_kernel', 'gz_rowlen_kernel'):
-        tot += sum(last) / len(last)
-print("sum of pipeline kernels %.1f us" % tot)
+    per = len(v) // steps                            # launches of this kernel per launch of the pipeline (gz_scan32_kernel: 2)
+    last = v[-3 * max(per, 1):]
+    avg = sum(last) / len(last)
+    note = "" if per else "   (not part of every launch: the load-time table build)"
+    print("%-24s n=%d last3 avg %8.1f us%s%s" % (k, len(v), avg, " x %d per launch" % per if per > 1 else "", note))
+    tot += avg * per
+print("sum of pipeline kernels per launch %.1f us" % tot)
