@@ -10,6 +10,7 @@ from typing import List, Optional, Sequence
 import numpy as np
 
 from . import _native
+from ._packing import pack as _pack
 
 OPS = {"html": _native.GZ_PP_HTML, "unicode": _native.GZ_PP_UNICODE, "punct": _native.GZ_PP_PUNCT,
        "emoji": _native.GZ_PP_EMOJI, "url": _native.GZ_PP_URL}
@@ -21,19 +22,6 @@ def _context() -> _native.Context:
     if _ctx is None:
         _ctx = _native.Context()
     return _ctx
-
-
-def _pack(texts: Sequence[str]):
-    parts = []
-    for t in texts:
-        if not isinstance(t, str):
-            raise TypeError("expected string or bytes-like object")      # what `re` / iteration raise in the reference
-        parts.append(t.encode("utf-8", "surrogatepass"))
-    off = np.zeros(len(parts) + 1, dtype=np.int64)
-    if parts:
-        np.cumsum([len(p) for p in parts], out=off[1:])
-    buf = np.frombuffer(b"".join(parts), dtype=np.uint8) if off[-1] else np.zeros(0, dtype=np.uint8)
-    return buf, off
 
 
 def preprocess_packed(text: np.ndarray, offsets: np.ndarray, ops: Sequence[str], ctx: Optional[_native.Context] = None):

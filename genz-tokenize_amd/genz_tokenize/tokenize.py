@@ -18,6 +18,7 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 
 from . import _native
+from ._packing import pack as _pack            # list of str -> packed UTF-8 + offsets (C when built)
 
 _DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
 
@@ -36,18 +37,6 @@ def _require_str(x):
     if isinstance(x, (bytes, bytearray, memoryview)):
         raise TypeError("cannot use a string pattern on a bytes-like object")
     raise TypeError("expected string or bytes-like object")
-
-
-def _pack(texts: Sequence[str]):
-    parts = []
-    off = np.zeros(len(texts) + 1, dtype=np.int64)
-    for i, t in enumerate(texts):
-        _require_str(t)
-        b = t.encode("utf-8", "surrogatepass")
-        parts.append(b)
-        off[i + 1] = off[i] + len(b)
-    buf = np.frombuffer(b"".join(parts), dtype=np.uint8) if off[-1] else np.zeros(0, dtype=np.uint8)
-    return buf, off
 
 
 class Tokenize(object):

@@ -51,3 +51,28 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h", ".inc")):
                 text = open(os.path.join(dirpath, f), encoding="utf-8", errors="replace").read()
                 assert "gz_oracle" not in text and "oracle/" not in text, os.path.join(dirpath, f)
+
+
+def test_string_packer_matches_python_encoding():
+    """csrc/gz_pack.c (host-side packing of list[str] for the batch calls) against `str.encode("utf-8", "surrogatepass")`:
+    ASCII, Latin-1, BMP, astral, lone surrogates, empty strings, tuples; a non-str item raises the reference's TypeError."""
+    import random
+    import numpy as np
+    _packing = pytest.importorskip("genz_tokenize._packing")
+    if _packing._gz_pack is None:
+        pytest.skip("_gz_pack is not built (make -C genz-tokenize_amd/csrc pack)")
+    r = random.Random(5)
+    alphabet = ["a", " ", "z", "\x7f", "\x80", "\xff", "Ā", "߿", "ࠀ", "ấ", "￿", "\ud800", "\udfff",
+                "\U00010000", "\U0001F600", "\U0010FFFF", "\n", "　"]
+    docs = ["".join(r.choice(alphabet) for _ in range(r.choice([0, 1, 2, 5, 17, 200]))) for _ in range(3000)]
+    for seq in (docs, tuple(docs[:50]), [], ["only ascii"] * 9, ["\xe9"] * 9):
+        b, o = _packing._gz_pack.pack(seq)
+        parts = [d.encode("utf-8", "surrogatepass") for d in seq]
+        assert b == b"".join(parts)
+        assert np.frombuffer(o, np.int64).tolist() == [0] + np.cumsum([len(p) for p in parts], dtype=np.int64).tolist()
+    buf, off = _packing.pack(docs)
+    assert buf.tobytes() == b"".join(d.encode("utf-8", "surrogatepass") for d in docs)
+    assert off.dtype == np.int64 and len(off) == len(docs) + 1
+    for bad in (["a"] * 8 + [3], ["a"] * 8 + [b"x"], ["a"] * 8 + [None]):
+        with pytest.raises(TypeError, match="expected string or bytes-like object"):
+            _packing.pack(bad)
