@@ -312,8 +312,10 @@ int setup_text(gz_ctx* c, gz_ctx::TextWs& W, DBuf& tiny, const uint8_t* tb, cons
     X.blklong = (uint32_t*)W.blklong.p; X.tilecnt = (uint16_t*)W.tilecnt.p;
     X.ctl = (uint32_t*)W.wlist.p; X.wlist = X.ctl + 4;                        // (one memset clears both)
     X.lookback = (uint64_t*)W.lookback.p;
-    X.epoch = ++c->lb_epoch;
-    if ((X.epoch & 0x3FFFFFFFu) == 0) X.epoch = ++c->lb_epoch;               // (0 is what a fresh allocation may hold)
+    // call numbers of the chained scans of this text: X.epoch (gz_split_kernel), + 1 and + 2 (gz_scan32m_kernel); they are
+    // 1, 2, 3 mod 4, so never 0 in their low 30 bits (0 is what a fresh allocation may hold)
+    c->lb_epoch += 4;
+    X.epoch = c->lb_epoch + 1;
     return GZ_OK;
 }
 

@@ -276,7 +276,9 @@ def test_big_pipeline_on_small_inputs():
     child process, so that both forms stay pinned to the reference on the hostile small cases."""
     import subprocess
     import sys
-    env = dict(os.environ, GZ_SMALL="0")
+    # (GZ_SCAN_MULTI=0: the block-count scans go through the chained multi-workgroup kernel whatever the size -- large
+    # batches use it by default, here it also sees one-chunk and few-element inputs)
+    env = dict(os.environ, GZ_SMALL="0", GZ_SCAN_MULTI="0")
     here = os.path.abspath(__file__)
     r = subprocess.run([sys.executable, "-m", "pytest", here, "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider", "-k",
                         "g1_cases or g3_random or g4_loader or cfg2_10k or cfg3_20k or noisy_corpus or long_and_huge or random_tables_fuzz or extreme_batch"],
