@@ -106,7 +106,7 @@ struct gz_ctx {
     int rank = 0, world = 1;
 
     DBuf t_words2, t_words0;
-    struct TextWs { DBuf brk, st, en, blkcnt, docw0, wtok, waux, mtok, mlist, blkmiss, blklong, tilecnt, wlist, grpblk, lookback; } tw[2][2];
+    struct TextWs { DBuf brk, st, en, blkcnt, docw0, wtok, waux, mtok, mlist, blkmiss, tilecnt, wlist, grpblk, lookback; } tw[2][2];
     uint32_t lb_epoch = 0;               // call number of the chained scan (gz_split_kernel)   // [slot][text]
     hipStream_t stream2 = nullptr;       // sub-batches alternate between the two streams
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -295,22 +295,23 @@ int setup_text(gz_ctx* c, gz_ctx::TextWs& W, DBuf& tiny, const uint8_t* tb, cons
     X.nblk = Bt / 4096 + 1;
     const size_t bm = (size_t)((Bt + 1024) / 1024) * 128 + 64 + 4096;
     int64_t wmax = Bt / 2 + n_docs + 2; if (wmax > Bt + 2) wmax = Bt + 2;
+    const int64_t nbr = (X.nblk + 2 + 3) & ~(int64_t)3;                       // block flags, then the control words, then the wide-word list: one buffer
     int rc2;
     if ((rc2 = ensure(c, W.brk, bm)) || (rc2 = ensure(c, W.st, bm)) || (rc2 = ensure(c, W.en, bm)) ||
         (rc2 = ensure(c, W.blkcnt, (size_t)(X.nblk + 2) * 4)) || (rc2 = ensure(c, W.docw0, (size_t)(n_docs + 2) * 4)) ||
         (rc2 = ensure(c, W.wtok, (size_t)wmax * 4)) || (rc2 = ensure(c, W.waux, (size_t)wmax * 4)) ||
         (rc2 = ensure(c, W.mtok, (size_t)(Bt + 32) * 4)) || (rc2 = ensure(c, W.mlist, (size_t)wmax * 16)) ||
         (rc2 = ensure(c, W.grpblk, (size_t)(wmax / 64 + 4) * 4)) ||
-        (rc2 = ensure(c, W.blkmiss, (size_t)(X.nblk + 2) * 4)) || (rc2 = ensure(c, W.blklong, (size_t)(X.nblk + 2) * 4)) ||
-        (rc2 = ensure(c, W.tilecnt, (size_t)(X.nblk + 2) * 8)) || (rc2 = ensure(c, W.wlist, (size_t)(wmax + 8) * 4)) ||
+        (rc2 = ensure(c, W.blkmiss, (size_t)(X.nblk + 2) * 4)) ||
+        (rc2 = ensure(c, W.tilecnt, (size_t)(X.nblk + 2) * 8)) || (rc2 = ensure(c, W.wlist, (size_t)(nbr + 4 + wmax + 8) * 4)) ||
         (rc2 = ensure(c, W.lookback, (size_t)(X.nblk / 4 + 4) * 8)))
         return rc2;
     X.brk = (uint16_t*)W.brk.p; X.st = (uint16_t*)W.st.p; X.en = (uint16_t*)W.en.p;
     X.blkcnt = (uint32_t*)W.blkcnt.p; X.docw0 = (uint32_t*)W.docw0.p;
     X.wtok = (uint32_t*)W.wtok.p; X.waux = (uint32_t*)W.waux.p; X.mtok = (int32_t*)W.mtok.p;
     X.mlist = (uint4*)W.mlist.p; X.grpblk = (uint32_t*)W.grpblk.p; X.wmax = wmax; X.blkmiss = (uint32_t*)W.blkmiss.p;
-    X.blklong = (uint32_t*)W.blklong.p; X.tilecnt = (uint16_t*)W.tilecnt.p;
-    X.ctl = (uint32_t*)W.wlist.p; X.wlist = X.ctl + 4;                        // (one memset clears both)
+    X.tilecnt = (uint16_t*)W.tilecnt.p;
+    X.blklong = (uint32_t*)W.wlist.p; X.ctl = X.blklong + nbr; X.wlist = X.ctl + 4;      // (ONE memset clears the flags, ctl[0..3] and the list's count)
     X.lookback = (uint64_t*)W.lookback.p;
     // call numbers of the chained scans of this text: X.epoch (gz_split_kernel), + 1 and + 2 (gz_scan32m_kernel); they are
     // 1, 2, 3 mod 4, so never 0 in their low 30 bits (0 is what a fresh allocation may hold)
@@ -640,7 +641,7 @@ void gz_destroy(gz_ctx* c)
                     &c->w_nreal, &c->w_status, &c->w_raw, &c->w_arena, &c->w_flags, &c->w_word, &c->w_wordout})
         release(*b);
     for (auto& slot : c->tw) for (auto& t : slot)
-        for (DBuf* b : {&t.brk, &t.st, &t.en, &t.blkcnt, &t.docw0, &t.wtok, &t.waux, &t.mtok, &t.mlist, &t.blkmiss, &t.blklong, &t.tilecnt, &t.wlist, &t.grpblk, &t.lookback}) release(*b);
+        for (DBuf* b : {&t.brk, &t.st, &t.en, &t.blkcnt, &t.docw0, &t.wtok, &t.waux, &t.mtok, &t.mlist, &t.blkmiss, &t.tilecnt, &t.wlist, &t.grpblk, &t.lookback}) release(*b);
     for (auto& ev : c->ev) if (ev) hipEventDestroy(ev);
     for (auto& pr : c->ring) { if (pr[0]) hipEventDestroy(pr[0]); if (pr[1]) hipEventDestroy(pr[1]); }
     if (c->h_flags) hipHostFree(c->h_flags);
