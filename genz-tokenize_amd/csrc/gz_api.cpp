@@ -537,7 +537,7 @@ static int build_word_table(gz_ctx* c)
     if (found0.empty()) return GZ_OK;            // (the 13..32-byte table is only consulted for misses of the first)
     {
         size_t slots0 = 16;
-        while (slots0 < GZ_TAB_SLACK * found0.size()) slots0 <<= 1;
+        while (slots0 < gz_tab_slack() * found0.size()) slots0 <<= 1;
         std::vector<GzWordSlot0> tab0(slots0, GzWordSlot0{0, 0, 0});
         for (const GzWordSlot0& e : found0) {
             size_t h = gz_word_hash0(e.lo, e.hi, e.meta & 15u) & (slots0 - 1);
@@ -551,7 +551,7 @@ static int build_word_table(gz_ctx* c)
     }
     if (!found2.empty()) {
         size_t slots2 = 16;
-        while (slots2 < GZ_TAB_SLACK * found2.size()) slots2 <<= 1;
+        while (slots2 < gz_tab_slack() * found2.size()) slots2 <<= 1;
         std::vector<GzWordSlot2> tab2(slots2, GzWordSlot2{{0, 0, 0, 0}, 0, 0, {0, 0, 0, 0, 0, 0}});
         for (const GzWordSlot2& e : found2) {
             size_t h = gz_word_hash2(e.k, e.len) & (slots2 - 1);

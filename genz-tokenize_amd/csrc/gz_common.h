@@ -1,6 +1,7 @@
 // Shared between the host table builder (gz_tables.cpp), the kernels (gz_kernels.hip) and the C ABI (gz_api.cpp).
 #pragma once
 #include <cstdint>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -43,6 +44,18 @@ GZ_HD uint32_t gz_cp_hash(uint32_t cp)
 #ifndef GZ_TAB_SLACK
 #define GZ_TAB_SLACK 16
 #endif
+// (the environment variable GZ_TAB_SLACK = 2 .. 64 overrides it when the tables are built: the parity suite runs its
+// golden batches once more on tables at half load, where probe chains are long, so that the continue-probing paths of the
+// kernels stay exercised)
+inline size_t gz_tab_slack()
+{
+    static const size_t v = [] {
+        const char* e = getenv("GZ_TAB_SLACK");
+        const long k = e ? atol(e) : 0;
+        return (size_t)(k >= 2 && k <= 64 ? k : GZ_TAB_SLACK);
+    }();
+    return v;
+}
 struct GzPairSlot  { uint32_t left, right, merged, rank; };              // left == GZ_PAIR_EMPTY -> empty; 32-bit compares only
 struct GzMergeInfo { uint32_t left, right, merged, pad; };   // indexed by rank
 struct GzSymIds    { int32_t nonfinal, final_; };            // vocab id of  sym+"@@"  /  sym minus "</w>"

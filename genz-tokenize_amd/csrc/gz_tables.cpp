@@ -302,7 +302,7 @@ int gz_build_tables(const uint8_t* vocab, size_t vocab_len, const uint8_t* bpe, 
     // ---- pair hash -------------------------------------------------------------------------------------------------
     {
         size_t slots = 16;
-        while (slots < GZ_TAB_SLACK * pairs.size()) slots <<= 1;
+        while (slots < gz_tab_slack() * pairs.size()) slots <<= 1;
         uint32_t shift = 32;
         while ((size_t(1) << (32 - shift)) < slots) --shift;
         T.pair_tab.assign(slots, GzPairSlot{GZ_PAIR_EMPTY, 0, 0, 0});

@@ -287,6 +287,22 @@ def test_big_pipeline_on_small_inputs():
     assert " passed" in r.stdout and "failed" not in r.stdout
 
 
+def test_dense_hash_tables():
+    """The hash tables are built at 1/16 load (a wave's probe loop runs until its last lane is done: long chains cost),
+    so the continue-probing branches of the kernels almost never run on the default build.  GZ_TAB_SLACK=2 builds them at
+    half load, as rounds 1-2 had them: the golden batches, the 20 k-document digests, the noisy corpora (single and
+    pairs), long words and the small-kernel shapes run again that way in a child process."""
+    import subprocess
+    import sys
+    env = dict(os.environ, GZ_TAB_SLACK="2")
+    here = os.path.abspath(__file__)
+    r = subprocess.run([sys.executable, "-m", "pytest", here, "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider", "-k",
+                        "g1_cases or g3_random or cfg3_20k or noisy_corpus or noisy_pairs or long_and_huge or small_kernel_shapes or random_tables_fuzz"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
+
+
 def test_small_kernel_shapes(tok, oracle_tables, sampler):
     """The one-launch path on its edge shapes, against the C oracle: documents of exactly 4 096 bytes (one per workgroup),
     64 tiny documents per workgroup, empty documents, every max_len class (1, 2, 3, odd, 1 024), a long word, a word of

@@ -115,8 +115,9 @@ def test_host_builder_under_sanitizers():
         pytest.skip("libasan.so not found next to gcc")
     env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:halt_on_error=1",
                UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "host_asan_child.py")], env=env, capture_output=True, text=True,
-                       timeout=600)
-    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
-    assert "asan child ok" in r.stdout
-    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
+    for slack in ("16", "2"):                   # the pair hash at its default load and at half load (long probe chains)
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "host_asan_child.py")], env=dict(env, GZ_TAB_SLACK=slack),
+                           capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+        assert "asan child ok" in r.stdout
+        assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
