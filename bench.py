@@ -321,6 +321,9 @@ def main():
     dist = None
     if world > 1 or args.force_exchange:
         import torch.distributed as dist
+        if world == 1:                                           # --force-exchange without a launcher: a one-rank group
+            for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29531"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+                os.environ.setdefault(k, v)
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
 
     import corpus
