@@ -6,7 +6,7 @@ R=$PWD
 LIB=$R/genz-tokenize_amd/genz_tokenize/libgenz_tokenize_hip.so
 cp $LIB /tmp/orig.so
 cd /tmp && export TMPDIR=/tmp
-for rep in 1 2; do
+for rep in $(seq 1 ${REPS:-2}); do
   for so in "$@"; do
     tag=$(basename $so .so)_$rep
     cp $R/$so $LIB
