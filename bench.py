@@ -275,6 +275,11 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--docs", type=int, default=N_SHARDS * SHARD_DOCS, help="documents of the whole job (8 equal shards)")
     ap.add_argument("--no-gather", action="store_true", help="(diagnostic) skip the RCCL gather at N > 1")
+    ap.add_argument("--transport", choices=("rccl", "gloo"), default="rccl",
+                    help="exchange transport: rccl = gz_gather_rows (grouped ncclSend/ncclRecv over xGMI, the product path); gloo = the SAME "
+                         "exchange step with the blocks carried D2H -> torch.distributed gloo send/recv -> H2D (rehearsal of the N > 1 code on "
+                         "a box where RCCL cannot run, e.g. several ranks on one GPU)")
+    ap.add_argument("--device", type=int, default=None, help="HIP device of this rank (default: LOCAL_RANK); --device 0 puts every rank on one GPU")
     ap.add_argument("--force-exchange", action="store_true",
                     help="(diagnostic) run the multi-GPU exchange step even with one rank (launch through torch.distributed.run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -310,25 +315,34 @@ def main():
                 cpu["cpu_baseline_c"] = {"error": str(e)}
 
     # ---- workload (untimed): this rank's shards of the fixed job, generated before the GPU is touched ----------------
-    my_ids = list(range(N_SHARDS * rank // world, N_SHARDS * (rank + 1) // world))
+    sys.path.insert(0, os.path.join(ROOT, "genz-tokenize_amd"))
+    from genz_tokenize.distributed import rank_shards as _rank_shards
+    my_ids = _rank_shards(rank, world, N_SHARDS)
     t_gen = time.perf_counter()
     made = make_shards(my_ids, shard_docs)
     t_gen = time.perf_counter() - t_gen
     L = made[0][3]
 
     import torch
-    torch.cuda.set_device(local_rank)
+    device = local_rank if args.device is None else args.device
+    torch.cuda.set_device(device)
+    gloo = args.transport == "gloo"
     dist = None
     if world > 1 or args.force_exchange:
         import torch.distributed as dist
         if world == 1:                                           # --force-exchange without a launcher: a one-rank group
             for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29531"), ("RANK", "0"), ("WORLD_SIZE", "1")):
                 os.environ.setdefault(k, v)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if gloo:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
+    cdev = "cpu" if gloo else "cuda"                             # where the few control scalars of the collectives live
 
     import corpus
     from genz_tokenize import Tokenize, _native
-    tok = Tokenize(device=local_rank)
+    from genz_tokenize.distributed import rank_shards, global_shard_id, GatherRound
+    tok = Tokenize(device=device)
     tok._sync_tables()
     ctx = tok._ctx
     flags = _native.GZ_PADDING | _native.GZ_TRUNCATION | _native.GZ_TIMING
@@ -352,35 +366,63 @@ def main():
     m = len(shards)                                               # shards per rank (the same on every rank: 8 / G)
     n = shards[0]["n"]
 
-    # root side of the exchange: round j gathers local shard j of every rank (global shard q * m + j comes from rank q)
-    rounds = [{"nreal": 0, "comp": 0, "cap": 0, "totals": None, "words": None} for _ in range(m)]
+    # root side of the exchange: round j gathers local shard j of every rank (global shard global_shard_id(q, j) comes from
+    # rank q); the bookkeeping -- block sizes, offsets, receive-buffer growth -- is genz_tokenize.distributed.GatherRound
+    rounds = [{"nreal": 0, "comp": 0, "plan": GatherRound(world, xbits)} for _ in range(m)]
     if gather:
-        uid = [ctx.comm_unique_id() if rank == 0 else None]
-        dist.broadcast_object_list(uid, src=0)
-        ctx.comm_init(uid[0], rank, world)
+        if not gloo:
+            uid = [ctx.comm_unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(uid, src=0)
+            ctx.comm_init(uid[0], rank, world)
         if rank == 0:
             for r in rounds:
                 r["nreal"] = ctx.alloc(4 * n * world)
+
+    def gloo_gatherv(d_src, my_words, d_dst, words):
+        """The gatherv of gz_gather_rows over gloo: this rank's `my_words` int32 words leave the device, travel by
+        torch.distributed send/recv, and land in the root's device buffer in rank order."""
+        mine = np.empty(my_words, dtype=np.int32)
+        if my_words:
+            ctx.d2h(mine, d_src)
+        if rank != 0:
+            if my_words:
+                dist.send(torch.from_numpy(mine), dst=0)
+            return
+        w0 = 0
+        for q in range(world):
+            k = int(words[q])
+            if k:
+                if q == 0:
+                    buf = mine
+                else:
+                    t_ = torch.empty(k, dtype=torch.int32)
+                    dist.recv(t_, src=q)
+                    buf = t_.numpy()
+                ctx.h2d(d_dst + 4 * w0, buf)
+            w0 += k
 
     def exchange(j, st):
         """Exchange step of local shard j: every rank sends the shard's rows WITHOUT the padding (row lengths + the rows'
         real entries, CSR form) straight to rank 0 over its own xGMI link (grouped ncclSend/ncclRecv)."""
         r = rounds[j]
+        plan = r["plan"]
         total = ctx.compact_rows(st["ids"], st["nreal"], n, L, st["comp"], bits=xbits)
-        t = torch.tensor([total], dtype=torch.int64, device="cuda")
+        t = torch.tensor([total], dtype=torch.int64, device=cdev)
         lst = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(lst, t)
-        totals = [int(x.item()) for x in lst]
-        words = [(t_ * xbits // 8 + 3) // 4 for t_ in totals]      # blocks travel as int32 words
-        if rank == 0 and sum(words) > r["cap"]:
+        cap = plan.announce([int(x.item()) for x in lst])
+        if rank == 0 and cap != plan.capacity:                    # the receive buffer grows (first round, or a fuller shard)
             ctx.sync()
             if r["comp"]:
                 ctx.free(r["comp"])
-            r["cap"] = int(sum(words) * 1.05) + 1024
-            r["comp"] = ctx.alloc(4 * r["cap"])
-        ctx.gather_rows(st["nreal"], n, 1, r["nreal"] if rank == 0 else 0, [n] * world, 0)
-        ctx.gather_rows(st["comp"], words[rank], 1, r["comp"], words, 0)
-        r["totals"], r["words"] = totals, words
+            r["comp"] = ctx.alloc(4 * cap)
+            plan.capacity = cap
+        if gloo:
+            gloo_gatherv(st["nreal"], n, r["nreal"] if rank == 0 else 0, [n] * world)
+            gloo_gatherv(st["comp"], plan.words[rank], r["comp"], plan.words)
+        else:
+            ctx.gather_rows(st["nreal"], n, 1, r["nreal"] if rank == 0 else 0, [n] * world, 0)
+            ctx.gather_rows(st["comp"], plan.words[rank], 1, r["comp"], plan.words, 0)
 
     kernel_ms = []
     step_no = [0]
@@ -419,7 +461,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     last_set = (step_no[0] - 1) % len(shards[0]["sets"])
@@ -458,10 +500,10 @@ def main():
     if gather and rank == 0 and not args.no_verify:
         d_ci, d_cm = ctx.alloc(4 * n * L), ctx.alloc(4 * n * L)
         for j, r in enumerate(rounds):
-            w0 = 0
+            plan = r["plan"]
             for q in range(world):
-                gid = N_SHARDS * q // world + j
-                ctx.expand_rows(r["comp"] + 4 * w0, r["nreal"] + 4 * n * q, n, L, d_ci, d_cm, bits=xbits)
+                gid = global_shard_id(q, j, world, N_SHARDS)
+                ctx.expand_rows(r["comp"] + 4 * plan.word_offset(q), r["nreal"] + 4 * n * q, n, L, d_ci, d_cm, bits=xbits)
                 ctx.sync()
                 blk = np.empty((n, L), dtype=np.int32); ctx.d2h(blk, d_ci)
                 mblk = np.empty((n, L), dtype=np.int32); ctx.d2h(mblk, d_cm)
@@ -476,18 +518,17 @@ def main():
                     k = int(row[-1])
                     e = None if (np.array_equal(wi[:k], blk.reshape(-1)) and np.array_equal(wm[:k], mblk.reshape(-1))) else \
                         "gathered block of rank %d (shard %d) differs from the C oracle" % (q, gid)
-                if int(mblk.sum(dtype=np.int64)) != r["totals"][q]:
+                if int(mblk.sum(dtype=np.int64)) != plan.totals[q]:
                     e = e or "gathered block of rank %d: ids received != ids announced" % q
                 if e:
                     errors.append(e)
                 checked.append("gathered shard %d (from rank %d)" % (gid, q))
-                w0 += r["words"][q]
                 del blk, mblk
         ctx.free(d_ci); ctx.free(d_cm)
 
     tot = np.array([sum(sh["in_bytes"] for sh in shards), tokens_local, sum(sh["n"] for sh in shards), len(errors)], dtype=np.float64)
     if dist is not None:
-        tt = torch.from_numpy(tot).cuda()
+        tt = torch.from_numpy(tot).to(cdev)
         dist.all_reduce(tt)
         tot = tt.cpu().numpy()
     total_bytes, total_tokens, total_docs, n_err = float(tot[0]), float(tot[1]), int(tot[2]), int(tot[3])
@@ -537,9 +578,11 @@ def main():
                                        total_docs, N_SHARDS, n, L, world, N_SHARDS, world, N_SHARDS, world),
                        "docs_total": total_docs, "input_bytes_total": int(total_bytes), "tokens_total": int(total_tokens),
                        "shards_per_rank": m, "launches_per_step_per_rank": m,
-                       "sharding": ("dp%d by documents (contiguous shards); exchange = RCCL gatherv (grouped send/recv over direct xGMI links) "
+                       "sharding": ("dp%d by documents (contiguous shards); exchange = %s "
                                     "of row lengths + unpadded ids (CSR, %d-bit entries) to rank 0, overlapped with the next shard's kernels%s" % (
-                                        world, xbits, "" if gather else " DISABLED (--no-gather)")) if world > 1 or gather else "single GPU: all 8 shards, one after the other",
+                                        world, "gatherv over torch.distributed gloo (D2H -> send/recv -> H2D: the REHEARSAL transport, not the product's)" if gloo
+                                        else "RCCL gatherv (grouped send/recv over direct xGMI links)", xbits,
+                                        "" if gather else " DISABLED (--no-gather)")) if world > 1 or gather else "single GPU: all 8 shards, one after the other",
                        "inputs": "resident in HBM before the timed region; outputs of every shard stay resident"},
             "roofline": {"bound": "hbm",
                          "kernel": "one launch of the pipeline = one shard of %d documents, on one stream: %s" % (n, PIPELINE),

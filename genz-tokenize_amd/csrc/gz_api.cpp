@@ -12,6 +12,8 @@
 #include <mutex>
 #include <new>
 #include <vector>
+#include <unordered_map>
+#include <algorithm>
 
 namespace {
 
@@ -106,9 +108,13 @@ struct gz_ctx {
     int rank = 0, world = 1;
 
     DBuf t_words2, t_words0;
-    struct TextWs { DBuf brk, st, en, blkcnt, docw0, wtok, waux, mtok, mlist, blkmiss, tilecnt, wlist, grpblk, lookback; } tw[2][2];
+    DBuf t_pair8, t_pair_disp, t_words0p, t_word0_disp;      // perfect-hash forms (gz_common.h)
+    DBuf t_pair_hot, t_word_hot;                             // hot sets the kernels stage in LDS
+    struct TextWs { DBuf brk, st, en, blkcnt, docw0, wtok, waux, mtok, mlist, blkmiss, tilecnt, wlist, grpblk, lookback, mq; } tw[2][2];
     uint32_t lb_epoch = 0;               // call number of the chained scan (gz_split_kernel)   // [slot][text]
     hipStream_t stream2 = nullptr;       // sub-batches alternate between the two streams
+    hipStream_t side = nullptr;          // the wide-word kernels of a text run here, beside the merge kernel
+    hipEvent_t ev_sf[2][2] = {}, ev_sj[2][2] = {};    // [slot][text]: fork / join of the side stream
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // exchange step (compact / gather / expand) on its own stream, so that it overlaps the next call's kernels
     hipStream_t xstream = nullptr;
@@ -219,7 +225,7 @@ int enqueue(gz_ctx* c)
         hipStream_t sk = (k & 1) ? c->stream2 : s;
         const GzAsmArgs& S = p.subs[k];
         for (int tx = 0; tx < S.n_texts; ++tx)
-            gz_launch_pipeline_text(T, S.X[tx], S.n_docs, p.use_words, (int32_t*)c->w_flags.p + 3, sk);
+            gz_launch_pipeline_text(T, c->dev, S.X[tx], S.n_docs, p.use_words, (int32_t*)c->w_flags.p + 3, sk, c->side, c->ev_sf[k & 1][tx], c->ev_sj[k & 1][tx]);
         gz_launch_assemble(T, S, sk);
     }
     if (two) { HIPCHK(c, hipEventRecord(c->ev_join, c->stream2)); HIPCHK(c, hipStreamWaitEvent(s, c->ev_join, 0)); }
@@ -301,17 +307,19 @@ int setup_text(gz_ctx* c, gz_ctx::TextWs& W, DBuf& tiny, const uint8_t* tb, cons
         (rc2 = ensure(c, W.blkcnt, (size_t)(X.nblk + 2) * 4)) || (rc2 = ensure(c, W.docw0, (size_t)(n_docs + 2) * 4)) ||
         (rc2 = ensure(c, W.wtok, (size_t)wmax * 4)) || (rc2 = ensure(c, W.waux, (size_t)wmax * 4)) ||
         (rc2 = ensure(c, W.mtok, (size_t)(Bt + 32) * 4)) || (rc2 = ensure(c, W.mlist, (size_t)wmax * 16)) ||
-        (rc2 = ensure(c, W.grpblk, (size_t)(wmax / 64 + 4) * 4)) ||
+        (rc2 = ensure(c, W.grpblk, (size_t)(wmax / 64 + 4 + wmax / 1024 + 8) * 4)) ||
         (rc2 = ensure(c, W.blkmiss, (size_t)(X.nblk + 2) * 4)) ||
-        (rc2 = ensure(c, W.tilecnt, (size_t)(X.nblk + 2) * 8)) || (rc2 = ensure(c, W.wlist, (size_t)(nbr + 4 + wmax + 8) * 4)) ||
+        (rc2 = ensure(c, W.tilecnt, (size_t)(X.nblk + 2) * 8)) || (rc2 = ensure(c, W.wlist, (size_t)(nbr + 64 + wmax + 8) * 4)) ||
+        (rc2 = ensure(c, W.mq, (size_t)wmax * 16)) ||
         (rc2 = ensure(c, W.lookback, (size_t)(X.nblk / 4 + 4) * 8)))
         return rc2;
     X.brk = (uint16_t*)W.brk.p; X.st = (uint16_t*)W.st.p; X.en = (uint16_t*)W.en.p;
     X.blkcnt = (uint32_t*)W.blkcnt.p; X.docw0 = (uint32_t*)W.docw0.p;
     X.wtok = (uint32_t*)W.wtok.p; X.waux = (uint32_t*)W.waux.p; X.mtok = (int32_t*)W.mtok.p;
-    X.mlist = (uint4*)W.mlist.p; X.grpblk = (uint32_t*)W.grpblk.p; X.wmax = wmax; X.blkmiss = (uint32_t*)W.blkmiss.p;
+    X.mlist = (uint4*)W.mlist.p; X.grpblk = (uint32_t*)W.grpblk.p; X.tcnt = X.grpblk + wmax / 64 + 4; X.wmax = wmax; X.blkmiss = (uint32_t*)W.blkmiss.p;
     X.tilecnt = (uint16_t*)W.tilecnt.p;
-    X.blklong = (uint32_t*)W.wlist.p; X.ctl = X.blklong + nbr; X.wlist = X.ctl + 4;      // (ONE memset clears the flags, ctl[0..3] and the list's count)
+    X.blklong = (uint32_t*)W.wlist.p; X.ctl = X.blklong + nbr; X.wlist = X.ctl + 64;     // (ONE memset clears the flags, the control words and the list's count)
+    X.mq = (uint4*)W.mq.p;
     X.lookback = (uint64_t*)W.lookback.p;
     // call numbers of the chained scans of this text: X.epoch (gz_split_kernel), + 1 and + 2 (gz_scan32m_kernel); they are
     // 1, 2, 3 mod 4, so never 0 in their low 30 bits (0 is what a fresh allocation may hold)
@@ -517,6 +525,7 @@ static int build_word_table(gz_ctx* c)
     if (rc) return rc;
     std::vector<GzWordSlot2> found2;
     std::vector<GzWordSlot0> found0;
+    std::vector<GzWordSlot1> found1;                         // <= 16 bytes: the big pipeline's table
     for (int64_t i = 0; i < n; ++i) {
         if (row[i + 1] - row[i] != 3) continue;
         const int32_t id = ids[row[i] + 1];
@@ -524,6 +533,11 @@ static int build_word_table(gz_ctx* c)
         const uint32_t len = (uint32_t)(off[i + 1] - off[i]);
         uint8_t key[32] = {0};
         std::memcpy(key, text.data() + off[i], len);
+        if (len <= 16) {
+            GzWordSlot1 e1{0, 0, len | ((uint32_t)id << 5), {0, 0, 0}};
+            std::memcpy(&e1.lo, key, 8); std::memcpy(&e1.hi, key + 8, 8);
+            found1.push_back(e1);
+        }
         if (len <= 12) {
             GzWordSlot0 e{0, 0, len | ((uint32_t)id << 4)};
             std::memcpy(&e.lo, key, 8); std::memcpy(&e.hi, key + 8, 4);
@@ -548,6 +562,48 @@ static int build_word_table(gz_ctx* c)
         HIPCHK(c, hipStreamSynchronize(c->stream));          // (tab0 dies at the end of this block)
         c->dev.words0 = (const GzWordSlot0*)c->t_words0.p;
         c->dev.word0_mask = (uint32_t)slots0 - 1;
+    }
+    {
+        // the words of <= 16 bytes, perfectly hashed (the big pipeline's word kernel: one line per probe, gz_common.h)
+        std::vector<uint32_t> hb(found1.size()), slot_of;
+        for (size_t i = 0; i < found1.size(); ++i) hb[i] = gz_word1_hb(found1[i].lo, found1[i].hi, found1[i].meta & 31u);
+        auto ha = [](const void* ctx, size_t i, uint32_t k1, uint32_t k2) -> uint32_t {
+            const GzWordSlot1& e = (*static_cast<const std::vector<GzWordSlot1>*>(ctx))[i];
+            return gz_word1_ha(e.lo, e.hi, e.meta & 31u, k1, k2);
+        };
+        GzPhHost ph;
+        gz_ph_build(found1.size(), ha, &found1, hb.data(), ph, slot_of);
+        std::vector<GzWordSlot1> tabp(ph.slots, GzWordSlot1{0, 0, 0, {0, 0, 0}});
+        for (size_t i = 0; i < found1.size(); ++i) tabp[slot_of[i]] = found1[i];
+        if ((rc = upload(c, c->t_words0p, tabp)) || (rc = upload(c, c->t_word0_disp, ph.disp))) return rc;
+        HIPCHK(c, hipStreamSynchronize(c->stream));          // (the vectors die at the end of this block)
+        c->dev.words0p = (const GzWordSlot1*)c->t_words0p.p;
+        c->dev.word0_ph = GzPh{(const uint16_t*)c->t_word0_disp.p, ph.nbuckets, ph.bshift, ph.sshift, ph.slots - 1, ph.k1, ph.k2};
+        c->dev.word0_ovf = ph.n_overflow;
+        // hot set: the words the vocab file counts most often (no counts: the file's order), direct-mapped by the top bits of ha
+        std::unordered_map<std::string, uint64_t> weight;
+        {
+            bool any = false;
+            for (uint64_t h : H.enc_hint) if (h) { any = true; break; }
+            for (size_t i = 0; i < H.enc_words.size(); ++i) weight[H.enc_words[i]] = any ? H.enc_hint[i] : (uint64_t)(H.enc_words.size() - i);
+        }
+        std::vector<std::pair<uint64_t, uint32_t>> order(found0.size());
+        for (size_t i = 0; i < found0.size(); ++i) {
+            char key[12];
+            std::memcpy(key, &found0[i].lo, 8); std::memcpy(key + 8, &found0[i].hi, 4);
+            auto it = weight.find(std::string(key, found0[i].meta & 15u));
+            order[i] = {it == weight.end() ? 0 : it->second, (uint32_t)i};
+        }
+        std::sort(order.begin(), order.end(), [](const std::pair<uint64_t, uint32_t>& x, const std::pair<uint64_t, uint32_t>& y) { return x.first != y.first ? x.first > y.first : x.second < y.second; });
+        std::vector<GzWordSlot0> hot(GZ_WORD_HOT_SLOTS, GzWordSlot0{0, 0, 0});
+        for (const auto& o : order) {
+            const GzWordSlot0& e = found0[o.second];
+            GzWordSlot0& h = hot[gz_word1_ha(e.lo, e.hi, e.meta & 15u, ph.k1, ph.k2) >> GZ_WORD_HOT_SHIFT];
+            if (h.meta == 0) h = e;
+        }
+        if ((rc = upload(c, c->t_word_hot, hot))) return rc;
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        c->dev.word_hot = (const GzWordSlot0*)c->t_word_hot.p;
     }
     if (!found2.empty()) {
         size_t slots2 = 16;
@@ -603,6 +659,9 @@ int gz_create(int device_id, gz_ctx** out)
     hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking);
+    hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+    for (auto& a : c->ev_sf) for (auto& e : a) hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    for (auto& a : c->ev_sj) for (auto& e : a) hipEventCreateWithFlags(&e, hipEventDisableTiming);
     for (auto& e : c->ev_tok) hipEventCreateWithFlags(&e, hipEventDisableTiming);
     hipEventCreateWithFlags(&c->ev_x, hipEventDisableTiming);
     hipHostMalloc((void**)&c->h_pick, 256, hipHostMallocDefault);
@@ -622,6 +681,9 @@ void gz_destroy(gz_ctx* c)
     for (auto& e : c->ev_tok) if (e) hipEventDestroy(e);
     if (c->ev_x) hipEventDestroy(c->ev_x);
     if (c->xstream) hipStreamDestroy(c->xstream);
+    if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
+    for (auto& a : c->ev_sf) for (auto& e : a) if (e) hipEventDestroy(e);
+    for (auto& a : c->ev_sj) for (auto& e : a) if (e) hipEventDestroy(e);
     if (c->s_in) hipStreamDestroy(c->s_in);
     if (c->s_out) hipStreamDestroy(c->s_out);
     for (auto& e : c->ev_in) if (e) hipEventDestroy(e);
@@ -636,12 +698,13 @@ void gz_destroy(gz_ctx* c)
     for (DBuf* b : {&c->w_pp[0], &c->w_pp[1], &c->w_ppoff[0], &c->w_ppoff[1], &c->w_pplen, &c->w_ppaux, &c->w_pp_in, &c->w_pp_inoff}) release(*b);
     for (DBuf* b : {&c->t_dec_entries, &c->t_dec_bytes, &c->w_dec_ids, &c->w_dec_roff, &c->w_dec_rb, &c->w_dec_ooff, &c->w_dec_out}) release(*b);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+    for (DBuf* b : {&c->t_pair8, &c->t_pair_disp, &c->t_words0p, &c->t_word0_disp, &c->t_pair_hot, &c->t_word_hot}) release(*b);
     for (DBuf* b : {&c->t_pair, &c->t_merges, &c->t_symids, &c->t_bmp, &c->t_astral, &c->t_struct, &c->t_words2, &c->t_words0, &c->w_text, &c->w_toff, &c->w_pair,
                     &c->w_poff, &c->w_ids, &c->w_mask, &c->w_tt, &c->w_seq, &c->w_rowoff, &c->w_rowlen, &c->w_pairlen,
                     &c->w_nreal, &c->w_status, &c->w_raw, &c->w_arena, &c->w_flags, &c->w_word, &c->w_wordout})
         release(*b);
     for (auto& slot : c->tw) for (auto& t : slot)
-        for (DBuf* b : {&t.brk, &t.st, &t.en, &t.blkcnt, &t.docw0, &t.wtok, &t.waux, &t.mtok, &t.mlist, &t.blkmiss, &t.tilecnt, &t.wlist, &t.grpblk, &t.lookback}) release(*b);
+        for (DBuf* b : {&t.brk, &t.st, &t.en, &t.blkcnt, &t.docw0, &t.wtok, &t.waux, &t.mtok, &t.mlist, &t.blkmiss, &t.tilecnt, &t.wlist, &t.grpblk, &t.lookback, &t.mq}) release(*b);
     for (auto& ev : c->ev) if (ev) hipEventDestroy(ev);
     for (auto& pr : c->ring) { if (pr[0]) hipEventDestroy(pr[0]); if (pr[1]) hipEventDestroy(pr[1]); }
     if (c->h_flags) hipHostFree(c->h_flags);
@@ -676,6 +739,7 @@ int gz_load_tables(gz_ctx* c, const uint8_t* vocab, size_t vocab_len, const uint
     if ((rc = upload(c, c->t_symids, H.sym_ids))) return rc;
     if ((rc = upload(c, c->t_bmp, H.bmp))) return rc;
     if (!H.astral.empty()) { if ((rc = upload(c, c->t_astral, H.astral))) return rc; }
+    if ((rc = upload(c, c->t_pair8, H.pair8)) || (rc = upload(c, c->t_pair_disp, H.pair_ph.disp)) || (rc = upload(c, c->t_pair_hot, H.pair_hot))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     GzDeviceTables& D = c->dev;
     D.pair_tab = (const GzPairSlot*)c->t_pair.p;   D.pair_mask = (uint32_t)H.pair_tab.size() - 1;
@@ -688,6 +752,12 @@ int gz_load_tables(gz_ctx* c, const uint8_t* vocab, size_t vocab_len, const uint
     D.astral_mask = H.astral.empty() ? 0 : (uint32_t)H.astral.size() - 1;
     D.pad_id = H.special_ids[0]; D.bos_id = H.special_ids[1]; D.eos_id = H.special_ids[2]; D.unk_id = H.special_ids[4];
     D.words2 = nullptr; D.word2_mask = 0; D.words0 = nullptr; D.word0_mask = 0;
+    D.pair8 = (const GzPair8*)c->t_pair8.p;
+    D.pair_ph = GzPh{(const uint16_t*)c->t_pair_disp.p, H.pair_ph.nbuckets, H.pair_ph.bshift, H.pair_ph.sshift, H.pair_ph.slots - 1, H.pair_ph.k1, H.pair_ph.k2};
+    D.words0p = nullptr; D.word0_ph = GzPh{nullptr, 16, 28, 28, 15, 1, 1};
+    D.pair_ovf = H.pair_ph.n_overflow; D.word0_ovf = 0;
+    D.pair_hot = (const GzPair8*)c->t_pair_hot.p; D.pair_hot_shift = GZ_PAIR_HOT_SHIFT;
+    D.word_hot = nullptr; D.word_hot_shift = GZ_WORD_HOT_SHIFT;
     if (c->host.enc_words.size() >= (1u << 26)) return fail(c, GZ_E_LIMIT, "vocab has 2^26 or more entries");
     if ((rc = ensure(c, c->t_struct, sizeof(GzDeviceTables)))) return rc;
     HIPCHK(c, hipMemcpy(c->t_struct.p, &c->dev, sizeof(GzDeviceTables), hipMemcpyHostToDevice));
@@ -1043,7 +1113,7 @@ int gz_encode_batch_csr(gz_ctx* c, const uint8_t* text, const int64_t* text_off,
         HIPCHK(c, hipStreamWaitEvent(s, c->ev_in[k], 0));
         if ((rc = setup_text(c, c->tw[k & 1][0], c->w_tiny[k & 7][0], d_text + text_off[lo], d_off + lo, text_off[hi] - text_off[lo], A.n_docs, s, A.X[0])))
             return rc;
-        gz_launch_pipeline_text(T, A.X[0], A.n_docs, use_words, (int32_t*)c->w_flags.p + 3, s);
+        gz_launch_pipeline_text(T, c->dev, A.X[0], A.n_docs, use_words, (int32_t*)c->w_flags.p + 3, s, c->side, c->ev_sf[k & 1][0], c->ev_sj[k & 1][0]);
         gz_launch_assemble(T, A, s);
         uint32_t* off32 = (uint32_t*)c->w_csr_off32.p;
         gz_launch_row_offsets(A.n_real, A.n_docs, off32, s);

@@ -20,7 +20,7 @@
 //                  bit 30 = it is the word's last character).  It can never merge and maps to the unk id.
 // ---------------------------------------------------------------------------------------------------------
 constexpr uint32_t GZ_MAX_SYMBOLS = (1u << 20) - 2;   // ids 0 .. 2^20-3; 0xFFFFF is reserved (empty key)
-constexpr uint32_t GZ_MAX_RANKS   = (1u << 24) - 1;   // merge-file line numbers
+constexpr uint32_t GZ_MAX_RANKS   = (1u << 23) - 1;   // merge-file line numbers (23 bits in a GzPair8 entry)
 constexpr uint32_t GZ_SYM_UNKNOWN = 0x80000000u;
 constexpr uint32_t GZ_SYM_LASTBIT = 0x40000000u;
 constexpr uint32_t GZ_NO_SYMBOL   = 0xFFFFFFFFu;      // table entry: code point has no interned symbol
@@ -57,6 +57,39 @@ inline size_t gz_tab_slack()
     return v;
 }
 struct GzPairSlot  { uint32_t left, right, merged, rank; };              // left == GZ_PAIR_EMPTY -> empty; 32-bit compares only
+
+// ---------------------------------------------------------------------------------------------------------
+// Static perfect hashing (hash and displace) for the tables the two hot kernels probe once per word / once per
+// adjacent pair.  The tables never change after gz_load_tables, so the host places every key where ONE load finds it:
+//     bucket = ha(key) >> bshift;   d = disp[bucket];   slot = ((hb(key) ^ d) * GZ_PH_MUL) >> sshift
+// `disp` (16 bits per bucket, <= GZ_PH_LDS_BUCKETS buckets) is staged in LDS once per workgroup: a probe is one
+// ds_read_u16 and ONE global load from a DENSE table (load <= 0.8) that stays resident in every XCD's L2 -- no probe
+// loop, no tail, no empty-slot slack.  The key is always compared in full, so what a probe returns never depends on
+// the hash functions.  A bucket the builder could not place (never seen on real tables; forced by the tests through
+// GZ_PH_FORCE_OVERFLOW) gets d = GZ_PH_OVERFLOW: its keys are inserted by linear probing from their slot, and only
+// lookups that land in such a bucket ever probe further.
+// ---------------------------------------------------------------------------------------------------------
+constexpr uint32_t GZ_PH_MUL = 0x2C1B3C6Du;
+constexpr uint32_t GZ_PH_OVERFLOW = 0xFFFFu;
+constexpr uint32_t GZ_PH_LDS_BUCKETS = 16384;                 // displacement entries a workgroup stages in LDS (32 KB)
+constexpr uint32_t GZ_PAIR_HOT_SLOTS = 4096, GZ_PAIR_HOT_SHIFT = 20;      // 32 KB of LDS
+constexpr uint32_t GZ_WORD_HOT_SLOTS = 2048, GZ_WORD_HOT_SHIFT = 21;      // 32 KB of LDS
+struct GzPh {
+    const uint16_t* disp;                                     // [nbuckets] (device copy)
+    uint32_t nbuckets, bshift;                                // bucket = ha >> bshift      (nbuckets = 2^(32 - bshift) >= 16)
+    uint32_t sshift, mask;                                    // slot = (...) >> sshift     (slots = mask + 1 = 2^(32 - sshift) >= 16)
+    uint32_t k1, k2;                                          // seeded multipliers of ha (the builder retries with other seeds)
+};
+GZ_HD uint32_t gz_ph_slot(uint32_t hb, uint32_t d, uint32_t sshift) { return ((hb ^ d) * GZ_PH_MUL) >> sshift; }
+// pair (a, b), both < 2^20.  (ha, hb) is an invertible linear map of (a, b) mod 2^32 for odd k1, k2 (the determinant
+// k1 * 0x27D4EB2F - k2 * 0xC2B2AE36 is odd): two pairs never share both hashes
+GZ_HD uint32_t gz_pair_ha(uint32_t a, uint32_t b, uint32_t k1, uint32_t k2) { return a * k1 + b * k2; }
+GZ_HD uint32_t gz_pair_hb(uint32_t a, uint32_t b) { return a * 0xC2B2AE36u + b * 0x27D4EB2Fu; }
+// Pair table entry, 8 bytes: lo = left | right << 20 (low 12 bits of right), hi = right >> 12 | flag << 8 | rank << 9.
+// Symbols are numbered so that the string a merge produces has the merge's rank as its id (gz_tables.cpp): the merged
+// symbol IS the rank unless two merge lines spell the same string -- then the flag is set and merges[rank].merged holds it.
+struct GzPair8 { uint32_t lo, hi; };                         // empty: {0xFFFFFFFF, 0xFFFFFFFF} (symbol 0xFFFFF is never interned)
+constexpr uint32_t GZ_PAIR8_ALIAS = 0x100u;                   // (hi >> 8 = rank << 1 | flag: ordered like the ranks)
 struct GzMergeInfo { uint32_t left, right, merged, pad; };   // indexed by rank
 struct GzSymIds    { int32_t nonfinal, final_; };            // vocab id of  sym+"@@"  /  sym minus "</w>"
 struct GzCpSyms    { uint32_t plain, final_; };              // symbol of  c  /  c+"</w>"   (GZ_NO_SYMBOL if none)
@@ -87,6 +120,23 @@ GZ_HD uint32_t gz_word_hash2(const uint64_t k[4], uint32_t len)
     return h;
 }
 
+// Whole-word table of the big pipeline's word kernel: words of <= 16 bytes (99.4 % of running text) in 32-byte slots,
+// perfectly hashed: key bytes 0..7, 8..15 (zero padded), meta = len:5 | id << 5 (0: empty).  One 128-byte line per probe.
+struct GzWordSlot1 { uint64_t lo, hi; uint32_t meta; uint32_t pad[3]; };
+// the two hashes of such a key
+GZ_HD uint32_t gz_word1_ha(uint64_t lo, uint64_t hi, uint32_t len, uint32_t k1, uint32_t k2)
+{
+    uint32_t h = (uint32_t)lo * k1 ^ (uint32_t)(lo >> 32) * k2 ^ (uint32_t)hi * 0xC2B2AE35u ^ ((uint32_t)(hi >> 32) + len) * 0x165667B1u;
+    h ^= h >> 15;
+    h *= 0x2C1B3C6Du;
+    return h;                                                 // (only the top bits are used: the bucket, the hot slot)
+}
+GZ_HD uint32_t gz_word1_hb(uint64_t lo, uint64_t hi, uint32_t len)
+{
+    const uint32_t a = (uint32_t)lo, b = (uint32_t)(lo >> 32), c = (uint32_t)hi, d = (uint32_t)(hi >> 32);
+    return a ^ ((b << 11) | (b >> 21)) ^ ((c << 21) | (c >> 11)) ^ ((d << 5) | (d >> 27)) ^ (len << 27);
+}
+
 // Device-resident tables, passed to kernels by value.
 struct GzDeviceTables {
     const GzPairSlot*  pair_tab;    uint32_t pair_mask;      // slots-1 (power of two; >= 16 slots)
@@ -98,7 +148,25 @@ struct GzDeviceTables {
     int32_t pad_id, bos_id, eos_id, unk_id;
     const GzWordSlot0* words0;      uint32_t word0_mask;     // whole-word table, <= 12 bytes (nullptr until built)
     const GzWordSlot2* words2;      uint32_t word2_mask;     // whole-word table, 13..32 bytes (may be nullptr)
+    // perfect-hash forms (the big pipeline's word and merge kernels)
+    const GzPair8*     pair8;       GzPh pair_ph;             // pair -> rank (= merged symbol)
+    const GzWordSlot1* words0p;     GzPh word0_ph;            // whole-word table, <= 16 bytes (nullptr until built)
+    uint32_t pair_ovf, word0_ovf;                             // keys in overflow buckets (0 on every real table: the kernels' fast forms)
+    // hot sets, staged in LDS by the two kernels (same entry layouts, direct-mapped, slot = top bits of ha): a probe that
+    // hits there costs no memory traffic -- a random probe of a table in L2 moves a whole 128-byte line for 8 or 16 bytes
+    const GzPair8*     pair_hot;    uint32_t pair_hot_shift;  // [2^(32 - shift)] the most frequent merges (smallest ranks)
+    const GzWordSlot0* word_hot;    uint32_t word_hot_shift;  // [2^(32 - shift)] the most frequent words (vocab counts / order)
 };
+
+// Host side of a perfect hash: hashes in, displacement array + the slot of every key out (gz_tables.cpp).
+struct GzPhHost {
+    std::vector<uint16_t> disp;
+    uint32_t nbuckets = 0, bshift = 0, sshift = 0, slots = 0, k1 = 0, k2 = 0;
+    uint32_t n_overflow = 0;                                  // keys placed by linear probing (0 on every table seen so far)
+};
+// ha(key index, k1, k2) and hb[key index]; slot_of[key] receives the key's slot.  Always succeeds.
+void gz_ph_build(size_t n, uint32_t (*ha)(const void* ctx, size_t i, uint32_t k1, uint32_t k2), const void* ctx,
+                 const uint32_t* hb, GzPhHost& out, std::vector<uint32_t>& slot_of);
 
 // Host-side result of the loader (tokenize.py:31-57) and of the table build.
 // ---- decoder snapshot (id -> word bytes), tokenize.py:40 -------------------------------------------------------------
@@ -131,6 +199,10 @@ struct GzHostTables {
     std::vector<GzCpSyms>    bmp;
     std::vector<GzAstral>    astral;     // empty when unused
     uint32_t max_probe = 0;
+    std::vector<GzPair8>     pair8;      // perfect-hash form of pair_tab
+    GzPhHost                 pair_ph;
+    std::vector<GzPair8>     pair_hot;   // direct-mapped hot set (GZ_PAIR_HOT_SLOTS entries)
+    std::vector<uint64_t>    enc_hint;   // per encoder entry: the count the vocab line carries (0: none) -- a speed hint only
 };
 
 // Returns GZ_OK / GZ_E_UTF8 / GZ_E_LIMIT; `err` receives a message.

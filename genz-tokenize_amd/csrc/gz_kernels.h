@@ -49,12 +49,16 @@ struct GzTextBufs {              // one text (A or B) of a batch and its per-cal
     uint4* mlist;                // [words] the misses of block b, compact, at mlist[blkcnt[b] ...]: {word index, byte offset, pending record, 0}
     uint32_t* blkmiss;           // [nblk+1] number of misses per block; scanned in place before gz_miss_kernel ([nblk] = total)
     uint32_t* grpblk;            // [words/64 + 2] block that holds miss number 64 g (written by the scan)
+    uint32_t* tcnt;              // [words/1024 + 2] records of every 1 024-miss tile of mq that the merge kernel takes (gz_mpre_kernel)
     int64_t wmax;                // upper bound of the number of words (sizes of the per-word arrays)
-    uint32_t* ctl;               // [4] zeroed per call: [1] ticket counter of gz_split_kernel; wlist == ctl + 4
+    uint32_t* ctl;               // [64] zeroed per call: [0] words for gz_long_kernel, [1] ticket counter of gz_split_kernel, [2] [3] of the
+                                 // chained scans, [8 + c] misses of class c, [32 + c] sort cursor of class c; wlist == ctl + 64
+    uint4* mq;                   // [words] the misses, tile by tile (1 024) sorted by symbol count: {word index, byte offset, record, 0}
     uint64_t* lookback;          // [nblk / 4 + 2] chained-scan words of gz_split_kernel {status:2, call:30, value:32}; never cleared
     uint32_t epoch;              // call number written into / expected in the chained-scan words
     uint32_t* blklong;           // [nblk] block holds a word for gz_long_kernel (zeroed per call)
-    uint32_t* wlist;             // [0] count, then the words (indices) that need 32 or 64 lanes (zeroed count per call)
+    uint32_t* wlist;             // [0] count, then the words (indices) that need 32 or 64 lanes (zeroed count per call); from the END of the
+                                 // array down (wlist[wmax + 6 - k]): the words gz_long_kernel takes
     uint16_t* tilecnt;           // [4 * nblk] word starts of the block that lie before each of its four 1-KiB tiles
     int32_t* mtok;               // [B+16]
 };
@@ -68,8 +72,11 @@ struct GzAsmArgs {
     int32_t docs_per_wave;
 };
 
-void gz_launch_pipeline_text(const GzDeviceTables* T_dev, const GzTextBufs& X, int64_t n_docs, int use_words,
-                             int32_t* long_flag /* device int, zeroed by the caller */, hipStream_t s);
+// T_host: the host copy of the table descriptor (table sizes decide launch shapes)
+// side / ev_fork / ev_join (may be null): a second stream on which the rare wide-word kernels run beside the merge kernel
+void gz_launch_pipeline_text(const GzDeviceTables* T_dev, const GzDeviceTables& T_host, const GzTextBufs& X, int64_t n_docs, int use_words,
+                             int32_t* long_flag /* device int, zeroed by the caller */, hipStream_t s,
+                             hipStream_t side = nullptr, hipEvent_t ev_fork = nullptr, hipEvent_t ev_join = nullptr);
 void gz_launch_pick(const int64_t* off, const int64_t* off2, int64_t n_docs, int nsub, int64_t* out /* 2*(nsub+1) */, hipStream_t s);
 void gz_launch_row_offsets(const int32_t* n_real, int64_t n_rows, uint32_t* off, hipStream_t s);
 void gz_launch_compact(const int32_t* rows, const uint32_t* off, int64_t n_rows, int32_t row_len, void* out, int bits /* 32 | 16 */, hipStream_t s);

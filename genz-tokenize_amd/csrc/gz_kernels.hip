@@ -481,6 +481,7 @@ void gz_launch_pick(const int64_t* off, const int64_t* off2, int64_t n_docs, int
 }
 
 #include "gz_pipeline.inc"
+#include "gz_hot.inc"
 #include "gz_small.inc"
 #include "gz_decode.inc"
 #include "gz_preproc.inc"

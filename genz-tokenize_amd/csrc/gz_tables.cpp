@@ -156,6 +156,7 @@ int gz_build_tables(const uint8_t* vocab, size_t vocab_len, const uint8_t* bpe, 
 
     // ---- encoder (tokenize.py:31-37, :44-51) ------------------------------------------------------------
     OrderedDict enc;
+    std::unordered_map<std::string, uint64_t> hint;
     for (int i = 0; i < 5; ++i) enc.set(specials[i], i);
     {
         size_t i = 0, n = vtext.size();
@@ -173,11 +174,24 @@ int gz_build_tables(const uint8_t* vocab, size_t vocab_len, const uint8_t* bpe, 
             else cut = (b > a) ? b - 1 : a;               // no space: line[:-1]; empty line: ''
             std::string word = to_utf8(vtext.data() + a, vtext.data() + cut);
             enc.set(word, (int32_t)enc.size());           // len(encoder) BEFORE the insertion
+            {
+                // what follows the last space is ignored by the reference; when it is a number (the bundled vocab: the
+                // word's corpus count) it is kept as a HINT for which words go into the kernels' LDS hot set
+                uint64_t cnt = 0;
+                bool digits = k > a && cut + 1 < b;
+                for (size_t q = cut + 1; q < b && digits; ++q) {
+                    if (vtext[q] < '0' || vtext[q] > '9' || cnt > (1ull << 56)) digits = false;
+                    else cnt = cnt * 10 + (uint64_t)(vtext[q] - '0');
+                }
+                hint[word] = digits ? cnt : 0;
+            }
             i = (j < n) ? j + 1 : j;
         }
     }
     T.enc_words = enc.keys;
     T.enc_ids = enc.vals;
+    T.enc_hint.assign(enc.keys.size(), 0);
+    for (size_t i = 0; i < enc.keys.size(); ++i) { auto it = hint.find(enc.keys[i]); if (it != hint.end()) T.enc_hint[i] = it->second; }
     for (int i = 0; i < 5; ++i) T.special_ids[i] = *enc.get(specials[i]);
     const int32_t unk_id = T.special_ids[4];
 
@@ -222,7 +236,28 @@ int gz_build_tables(const uint8_t* vocab, size_t vocab_len, const uint8_t* bpe, 
     }
 
     // ---- symbols --------------------------------------------------------------------------------------------
+    // Numbering: the string a merge produces gets the merge's RANK as its id (two lines that spell the same string: the
+    // smaller rank), so that a pair-table entry needs no separate "merged symbol" field; every other string (merge
+    // operands that no merge produces, single characters) is numbered from the number of lines up.  Ranks of lines that
+    // are no merges stay unused ids (empty strings).
     std::unordered_map<std::string, uint32_t> sym_of;
+    const size_t n_lines = T.merges.size();
+    struct Pair { uint32_t a, b, rank; };
+    std::vector<Pair> pairs;
+    struct Fields { std::string a, b; uint32_t rank; };
+    std::vector<Fields> two;
+    for (size_t k = 0; k < ranks.size(); ++k) {
+        if (T.rank_nfields[k] != 2) continue;             // such a key can never equal a (first, second) pair
+        const std::string& key = ranks.keys[k];
+        size_t nl = key.find('\n');
+        two.push_back(Fields{key.substr(0, nl), key.substr(nl + 1), (uint32_t)ranks.vals[k]});
+        const std::string m = two.back().a + two.back().b;
+        auto it = sym_of.find(m);
+        if (it == sym_of.end()) sym_of.emplace(m, two.back().rank);
+        else if (two.back().rank < it->second) it->second = two.back().rank;
+    }
+    T.symbols.assign(n_lines, std::string());
+    for (const auto& kv : sym_of) T.symbols[kv.second] = kv.first;
     auto intern = [&](const std::string& s) -> uint32_t {
         auto it = sym_of.find(s);
         if (it != sym_of.end()) return it->second;
@@ -231,17 +266,10 @@ int gz_build_tables(const uint8_t* vocab, size_t vocab_len, const uint8_t* bpe, 
         T.symbols.push_back(s);
         return id;
     };
-    struct Pair { uint32_t a, b, rank; };
-    std::vector<Pair> pairs;
-    for (size_t k = 0; k < ranks.size(); ++k) {
-        if (T.rank_nfields[k] != 2) continue;             // such a key can never equal a (first, second) pair
-        const std::string& key = ranks.keys[k];
-        size_t nl = key.find('\n');
-        std::string a = key.substr(0, nl), b = key.substr(nl + 1);
-        uint32_t ia = intern(a), ib = intern(b), im = intern(a + b);
-        uint32_t r = (uint32_t)ranks.vals[k];
-        T.merges[r] = GzMergeInfo{ia, ib, im, 0};
-        pairs.push_back({ia, ib, r});
+    for (const Fields& f : two) {
+        uint32_t ia = intern(f.a), ib = intern(f.b), im = intern(f.a + f.b);
+        T.merges[f.rank] = GzMergeInfo{ia, ib, im, 0};
+        pairs.push_back({ia, ib, f.rank});
     }
     // single-character forms the vocab knows: token "c" is the final piece of symbol c+"</w>", token "c@@" is
     // the non-final piece of symbol c
@@ -316,5 +344,111 @@ int gz_build_tables(const uint8_t* vocab, size_t vocab_len, const uint8_t* bpe, 
         }
         T.max_probe = worst;
     }
+    // ---- the same pairs, perfectly hashed: 8-byte entries, one load per probe ------------------------------------
+    {
+        std::vector<uint32_t> hb(pairs.size()), slot_of;
+        for (size_t i = 0; i < pairs.size(); ++i) hb[i] = gz_pair_hb(pairs[i].a, pairs[i].b);
+        auto ha = [](const void* ctx, size_t i, uint32_t k1, uint32_t k2) -> uint32_t {
+            const Pair& p = (*static_cast<const std::vector<Pair>*>(ctx))[i];
+            return gz_pair_ha(p.a, p.b, k1, k2);
+        };
+        gz_ph_build(pairs.size(), ha, &pairs, hb.data(), T.pair_ph, slot_of);
+        T.pair8.assign(T.pair_ph.slots, GzPair8{0xFFFFFFFFu, 0xFFFFFFFFu});
+        for (size_t i = 0; i < pairs.size(); ++i) {
+            const Pair& p = pairs[i];
+            const uint32_t merged = T.merges[p.rank].merged;
+            T.pair8[slot_of[i]] = GzPair8{p.a | (p.b << 20), (p.b >> 12) | (p.rank << 9) | (merged != p.rank ? GZ_PAIR8_ALIAS : 0u)};
+        }
+        // hot set: merges are learned most frequent first, so the smallest ranks are the pairs running text asks for most;
+        // direct-mapped by the top bits of ha, the smaller rank keeps a contested slot
+        T.pair_hot.assign(GZ_PAIR_HOT_SLOTS, GzPair8{0xFFFFFFFFu, 0xFFFFFFFFu});
+        std::vector<uint32_t> by_rank(pairs.size());
+        for (size_t i = 0; i < pairs.size(); ++i) by_rank[i] = (uint32_t)i;
+        std::sort(by_rank.begin(), by_rank.end(), [&](uint32_t x, uint32_t y) { return pairs[x].rank < pairs[y].rank; });
+        for (uint32_t i : by_rank) {
+            const Pair& p = pairs[i];
+            GzPair8& h = T.pair_hot[gz_pair_ha(p.a, p.b, T.pair_ph.k1, T.pair_ph.k2) >> GZ_PAIR_HOT_SHIFT];
+            if (h.lo == 0xFFFFFFFFu) h = T.pair8[slot_of[i]];
+        }
+    }
     return GZ_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Hash and displace.  Buckets are placed largest first; a bucket tries d = 0, 1, 2, ... until every one of its keys
+// lands on a free slot.  Tables stay at load <= 0.8 and buckets at about 8 keys on average (16 bits of displacement are
+// plenty: the bundled pair table needs d < 1000); a failed attempt is retried with other multipliers and then with
+// more buckets.  Keys of buckets that still cannot be placed (two keys with the same hb in one bucket under every
+// seed: adversarial tables only) are inserted by linear probing and their bucket is marked GZ_PH_OVERFLOW.
+// ---------------------------------------------------------------------------------------------------------------------
+void gz_ph_build(size_t n, uint32_t (*ha)(const void* ctx, size_t i, uint32_t k1, uint32_t k2), const void* ctx,
+                 const uint32_t* hb, GzPhHost& out, std::vector<uint32_t>& slot_of)
+{
+    size_t slots = 16;
+    while (slots * 4 < n * 5) slots <<= 1;                         // load <= 0.8
+    uint32_t sshift = 32;
+    while ((size_t(1) << (32 - sshift)) < slots) --sshift;
+    size_t nb0 = 16;
+    while (nb0 * 8 < n) nb0 <<= 1;
+    static const int force = [] { const char* e = getenv("GZ_PH_FORCE_OVERFLOW"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
+    GzPhHost best;
+    std::vector<uint32_t> best_slots;
+    bool have = false;
+    for (int attempt = 0; attempt < 12; ++attempt) {
+        // attempts 0..3: nb0 buckets with four seeds, 4..7: twice as many, 8..11: four times as many
+        size_t nb = nb0 << (attempt / 4);
+        if (nb > slots) nb = slots;
+        uint32_t bshift = 32;
+        while ((size_t(1) << (32 - bshift)) < nb) --bshift;
+        const uint32_t k1 = 0x9E3779B1u + 0x3C6EF372u * (uint32_t)attempt, k2 = 0x85EBCA6Bu + 0x1B873592u * (uint32_t)attempt;   // odd
+        std::vector<uint32_t> cnt(nb + 1, 0), bucket_of(n);
+        for (size_t i = 0; i < n; ++i) { bucket_of[i] = ha(ctx, i, k1, k2) >> bshift; ++cnt[bucket_of[i] + 1]; }
+        for (size_t b = 0; b < nb; ++b) cnt[b + 1] += cnt[b];
+        std::vector<uint32_t> keys(n), fill(cnt.begin(), cnt.end() - 1);
+        for (size_t i = 0; i < n; ++i) keys[fill[bucket_of[i]]++] = (uint32_t)i;
+        std::vector<uint32_t> order(nb);
+        for (size_t b = 0; b < nb; ++b) order[b] = (uint32_t)b;
+        std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return cnt[x + 1] - cnt[x] > cnt[y + 1] - cnt[y]; });
+        std::vector<uint8_t> used(slots, 0);
+        GzPhHost cur;
+        cur.disp.assign(nb, 0);
+        cur.nbuckets = (uint32_t)nb; cur.bshift = bshift; cur.sshift = sshift; cur.slots = (uint32_t)slots; cur.k1 = k1; cur.k2 = k2;
+        std::vector<uint32_t> cur_slots(n, 0), spill;
+        std::vector<uint32_t> tmp;
+        size_t nonempty = 0;
+        for (uint32_t b : order) {
+            const uint32_t lo = cnt[b], hi = cnt[b + 1];
+            if (lo == hi) break;
+            ++nonempty;
+            bool placed = false;
+            if (!(force && nonempty % (size_t)force == 0)) {
+                tmp.resize(hi - lo);
+                for (uint32_t d = 0; d < GZ_PH_OVERFLOW && !placed; ++d) {
+                    bool ok = true;
+                    for (uint32_t k = lo; k < hi && ok; ++k) {
+                        const uint32_t sl = gz_ph_slot(hb[keys[k]], d, sshift);
+                        if (used[sl]) ok = false;
+                        else { for (uint32_t j = lo; j < k; ++j) if (tmp[j - lo] == sl) { ok = false; break; } }
+                        tmp[k - lo] = sl;
+                    }
+                    if (ok) {
+                        for (uint32_t k = lo; k < hi; ++k) { used[tmp[k - lo]] = 1; cur_slots[keys[k]] = tmp[k - lo]; }
+                        cur.disp[b] = (uint16_t)d;
+                        placed = true;
+                    }
+                }
+            }
+            if (!placed) { cur.disp[b] = (uint16_t)GZ_PH_OVERFLOW; for (uint32_t k = lo; k < hi; ++k) spill.push_back(keys[k]); }
+        }
+        for (uint32_t i : spill) {                                    // linear probing from the slot d = GZ_PH_OVERFLOW gives
+            uint32_t sl = gz_ph_slot(hb[i], GZ_PH_OVERFLOW, sshift);
+            while (used[sl]) sl = (sl + 1) & (uint32_t)(slots - 1);
+            used[sl] = 1; cur_slots[i] = sl;
+        }
+        cur.n_overflow = (uint32_t)spill.size();
+        if (!have || cur.n_overflow < best.n_overflow) { best = std::move(cur); best_slots = std::move(cur_slots); have = true; }
+        if (best.n_overflow == 0 || force) break;
+    }
+    out = std::move(best);
+    slot_of = std::move(best_slots);
 }

@@ -43,3 +43,54 @@ class RcclTransport:
     def gather_rows(self, d_local: int, rows_per_rank, row_len, root=0, d_recv: int = 0):
         self.ctx.gather_rows(d_local, int(rows_per_rank[self.rank]), row_len, d_recv, rows_per_rank, root)
         return d_recv
+
+
+# ---- the fixed multi-shard job of bench.py (BASELINE configs[3]): who owns what, and the root's bookkeeping ------------
+def rank_shards(rank: int, world: int, n_shards: int) -> List[int]:
+    """Global shard ids rank `rank` of `world` owns: the contiguous range [n_shards * rank / world, n_shards * (rank + 1) /
+    world).  `world` must divide into the shards evenly enough that every rank owns at least one."""
+    if not (0 <= rank < world) or world > n_shards:
+        raise ValueError("rank %d of %d for %d shards" % (rank, world, n_shards))
+    return list(range(n_shards * rank // world, n_shards * (rank + 1) // world))
+
+
+def global_shard_id(peer: int, local_index: int, world: int, n_shards: int) -> int:
+    """Shard that arrives from rank `peer` in exchange round `local_index` (its local_index-th shard)."""
+    ids = rank_shards(peer, world, n_shards)
+    if not (0 <= local_index < len(ids)):
+        raise ValueError("rank %d owns %d shards; round %d" % (peer, len(ids), local_index))
+    return ids[local_index]
+
+
+def csr_words(n_entries: int, bits: int) -> int:
+    """int32 words a CSR block of `n_entries` entries of `bits` (16 | 32) bits travels as (blocks travel as whole words)."""
+    if bits not in (16, 32) or n_entries < 0:
+        raise ValueError("bits must be 16 or 32")
+    return (n_entries * bits // 8 + 3) // 4
+
+
+class GatherRound:
+    """Root-side state of ONE exchange round (local shard j of every rank): where each peer's block starts in the
+    receive buffer, how large the buffer must be, and what every peer announced."""
+
+    def __init__(self, world: int, bits: int, slack: float = 1.05, pad: int = 1024):
+        self.world, self.bits, self.slack, self.pad = world, bits, slack, pad
+        self.capacity = 0                 # int32 words the receive buffer currently holds
+        self.totals: List[int] = []       # entries announced by every rank
+        self.words: List[int] = []        # int32 words of every rank's block
+
+    def announce(self, totals: Sequence[int]) -> int:
+        """Record what the ranks announced for this round; returns the capacity (in int32 words) the receive buffer must
+        have -- the current one when it is enough, else the grown one (the caller re-allocates when it differs)."""
+        if len(totals) != self.world:
+            raise ValueError("%d totals for %d ranks" % (len(totals), self.world))
+        self.totals = [int(t) for t in totals]
+        self.words = [csr_words(t, self.bits) for t in self.totals]
+        need = sum(self.words)
+        if need > self.capacity:
+            return int(need * self.slack) + self.pad
+        return self.capacity
+
+    def word_offset(self, peer: int) -> int:
+        """int32 word at which rank `peer`'s block starts in the receive buffer (blocks lie in rank order)."""
+        return sum(self.words[:peer])

@@ -71,3 +71,49 @@ def test_gather_rows_world2_gloo():
         p.join(120)
         assert p.exitcode == 0
     assert q.get(timeout=5) is True
+
+
+def test_shard_ownership_and_root_bookkeeping():
+    """The root-side index arithmetic of the exchange step (bench.py uses exactly these helpers): who owns which shard,
+    which shard arrives from which peer in which round, block sizes in int32 words and their offsets, buffer growth."""
+    from genz_tokenize.distributed import rank_shards, global_shard_id, csr_words, GatherRound
+    n_shards = 8
+    for world in (1, 2, 4, 8):
+        owned = [rank_shards(r, world, n_shards) for r in range(world)]
+        assert sorted(s for o in owned for s in o) == list(range(n_shards))           # a partition, in order
+        assert all(len(o) == n_shards // world for o in owned)
+        assert all(o == list(range(o[0], o[0] + len(o))) for o in owned)              # contiguous
+        m = n_shards // world
+        seen = set()
+        for j in range(m):
+            for q in range(world):
+                gid = global_shard_id(q, j, world, n_shards)
+                assert gid == owned[q][j]
+                seen.add(gid)
+        assert seen == set(range(n_shards))
+    with pytest.raises(ValueError):
+        rank_shards(8, 8, 8)
+    with pytest.raises(ValueError):
+        rank_shards(0, 9, 8)
+    with pytest.raises(ValueError):
+        global_shard_id(0, 1, 8, 8)
+    assert [csr_words(t, 16) for t in (0, 1, 2, 3, 4, 5)] == [0, 1, 1, 2, 2, 3]
+    assert [csr_words(t, 32) for t in (0, 1, 2)] == [0, 1, 2]
+    rng = np.random.default_rng(3)
+    for world in (2, 4, 8):
+        for bits in (16, 32):
+            plan = GatherRound(world, bits)
+            cap_seen = 0
+            for _ in range(5):                                   # several steps: the buffer only ever grows
+                totals = [int(x) for x in rng.integers(0, 50_000, size=world)]
+                cap = plan.announce(totals)
+                assert cap >= sum(plan.words) and cap >= cap_seen
+                if cap != plan.capacity:
+                    plan.capacity = cap                          # (the caller re-allocates)
+                cap_seen = plan.capacity
+                assert plan.words == [csr_words(t, bits) for t in totals]
+                offs = [plan.word_offset(q) for q in range(world)]
+                assert offs[0] == 0 and all(offs[q + 1] - offs[q] == plan.words[q] for q in range(world - 1))
+                assert offs[-1] + plan.words[-1] <= plan.capacity
+            with pytest.raises(ValueError):
+                plan.announce([1] * (world + 1))

@@ -13,7 +13,7 @@ for rep in $(seq 1 ${REPS:-2}); do
     rm -rf /tmp/prof_$tag
     timeout -k 10 300 rocprofv3 --kernel-trace -d /tmp/prof_$tag -o t --output-format csv -- python3 $R/tools/prof_run.py ${NDOCS:-1000000} 5 > /tmp/prof_$tag.log 2>&1 || { tail -20 /tmp/prof_$tag.log; cp /tmp/orig.so $LIB; exit 1; }
     echo "== $tag: $(grep '^docs' /tmp/prof_$tag.log | sed 's/.*kernel ms//')"
-    python3 $R/tools/trace_summary.py /tmp/prof_$tag | grep -E "classify|scan32|docw0|brk|words_k|miss_k|miss_wide|rows|split|assemble|sum of" | awk '{v = $(NF-1); for (i = 1; i < NF; i++) if ($i == "avg") v = $(i+1); printf "%s %s | ", $1, v} END {print ""}'
+    python3 $R/tools/trace_summary.py /tmp/prof_$tag | grep -E "classify|scan32|docw0|brk|words|miss|mpre|rows|split|assemble|sum of" | awk '{v = $(NF-1); for (i = 1; i < NF; i++) if ($i == "avg") v = $(i+1); printf "%s %s | ", $1, v} END {print ""}'
   done
 done
 cp /tmp/orig.so $LIB
