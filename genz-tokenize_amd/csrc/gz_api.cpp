@@ -95,6 +95,7 @@ struct gz_ctx {
         const uint8_t* s_pair0 = nullptr; const int64_t* s_poff = nullptr; int64_t s_pbase = 0;
         int32_t s_max_len = 0; int32_t* s_ids = nullptr; int32_t* s_mask = nullptr; int32_t* s_nreal = nullptr; int32_t* s_arena = nullptr;
         bool keep_words = false;
+        bool chained = false;          // enqueued behind a call that has not been synchronised (its scan flag is kept)
     } pend;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     // timed calls that were chained without a host sync in between: start / end of the main kernels of the last RING
@@ -166,7 +167,9 @@ int fail(gz_ctx* c, int code, const char* fmt, ...)
         if (e_ != hipSuccess) return fail((c), GZ_E_HIP, "%s: %s", #call, hipGetErrorString(e_));    \
     } while (0)
 
-int ensure(gz_ctx* c, DBuf& b, size_t bytes)
+// zero_new: a fresh allocation is cleared before anything uses it (the chained-scan words are validated by a per-context
+// call number only: memory another context freed could otherwise carry words that look current)
+int ensure(gz_ctx* c, DBuf& b, size_t bytes, bool zero_new = false)
 {
     if (bytes <= b.cap && b.p) return GZ_OK;
     if (b.p) { hipFree(b.p); b.p = nullptr; b.cap = 0; }
@@ -175,6 +178,7 @@ int ensure(gz_ctx* c, DBuf& b, size_t bytes)
     hipError_t e = hipMalloc(&b.p, want);
     if (e != hipSuccess) { b.p = nullptr; return fail(c, GZ_E_NOMEM, "hipMalloc(%zu): %s", want, hipGetErrorString(e)); }
     b.cap = want;
+    if (zero_new && hipMemset(b.p, 0, want) != hipSuccess) return fail(c, GZ_E_HIP, "hipMemset of a new workspace buffer failed");
     return GZ_OK;
 }
 
@@ -210,7 +214,13 @@ int enqueue(gz_ctx* c)
     const GzDeviceTables* T = (const GzDeviceTables*)c->t_struct.p;
     if (c->x_used) HIPCHK(c, hipStreamWaitEvent(s, c->ev_x, 0));    // output buffers may still be read by an exchange step
     const bool no_flags = p.small && !p.ragged;                 // (a dense one-launch call raises no flag)
-    if (!no_flags) HIPCHK(c, hipMemsetAsync(c->w_flags.p, 0, 16, s));     // [0] scan time-out, [1] capacity error, [3] a word needs the wide / long kernels
+    // [0] scan time-out, [1] capacity error, [3] a word needs the wide / long kernels.  Calls chained without a host
+    // synchronisation keep [0]: it is only cleared when a chain starts, so a time-out in ANY call of the chain is still
+    // there when the chain is closed (sync_locked)
+    if (!no_flags) {
+        if (p.chained) HIPCHK(c, hipMemsetAsync((int32_t*)c->w_flags.p + 1, 0, 12, s));
+        else HIPCHK(c, hipMemsetAsync(c->w_flags.p, 0, 16, s));
+    }
     if (p.timing) {
         hipEvent_t* slot = c->ring[c->ring_n % gz_ctx::RING];
         if (!slot[0]) { HIPCHK(c, hipEventCreate(&slot[0])); HIPCHK(c, hipEventCreate(&slot[1])); }
@@ -238,7 +248,7 @@ int enqueue(gz_ctx* c)
     if (p.pair) gz_launch_pair(c->dev, p.P, s);
     if (p.timing) HIPCHK(c, hipEventRecord(c->ev[3], s));
     if (!no_flags) HIPCHK(c, hipMemcpyAsync(c->h_flags, c->w_flags.p, 8, hipMemcpyDeviceToHost, s));
-    else c->h_flags[0] = c->h_flags[1] = 0;
+    else if (!p.chained) c->h_flags[0] = c->h_flags[1] = 0;
     HIPCHK(c, hipEventRecord(c->ev_tok[c->enc_seq & 3], s));
     c->enc_seq++;
     HIPCHK(c, hipGetLastError());
@@ -273,7 +283,7 @@ int sync_locked(gz_ctx* c)
         hipEventElapsedTime(&ms, c->ev[0], c->ev[3]); c->timing[3] = ms;
     }
     p.active = false;
-    if (c->h_flags[0]) return fail(c, GZ_E_HIP, "internal: the chained scan of gz_split_kernel timed out");
+    if (c->h_flags[0]) return fail(c, GZ_E_HIP, "internal: a chained scan (gz_scan32m_kernel / gz_split_kernel look-back) timed out");
     if (c->h_flags[1]) return fail(c, GZ_E_CAPACITY, "ragged output larger than capacity");
     return GZ_OK;
 }
@@ -311,7 +321,7 @@ int setup_text(gz_ctx* c, gz_ctx::TextWs& W, DBuf& tiny, const uint8_t* tb, cons
         (rc2 = ensure(c, W.blkmiss, (size_t)(X.nblk + 2) * 4)) ||
         (rc2 = ensure(c, W.tilecnt, (size_t)(X.nblk + 2) * 8)) || (rc2 = ensure(c, W.wlist, (size_t)(nbr + 64 + wmax + 8) * 4)) ||
         (rc2 = ensure(c, W.mq, (size_t)wmax * 16)) ||
-        (rc2 = ensure(c, W.lookback, (size_t)(X.nblk / 4 + 4) * 8)))
+        (rc2 = ensure(c, W.lookback, (size_t)(X.nblk / 4 + 4) * 8, /* zero a new allocation */ true)))
         return rc2;
     X.brk = (uint16_t*)W.brk.p; X.st = (uint16_t*)W.st.p; X.en = (uint16_t*)W.en.p;
     X.blkcnt = (uint32_t*)W.blkcnt.p; X.docw0 = (uint32_t*)W.docw0.p;
@@ -324,6 +334,10 @@ int setup_text(gz_ctx* c, gz_ctx::TextWs& W, DBuf& tiny, const uint8_t* tb, cons
     // call numbers of the chained scans of this text: X.epoch (gz_split_kernel), + 1 and + 2 (gz_scan32m_kernel); they are
     // 1, 2, 3 mod 4, so never 0 in their low 30 bits (0 is what a fresh allocation may hold)
     c->lb_epoch += 4;
+    if ((c->lb_epoch & 0x3FFFFFFFu) < 4u) {                      // the 30-bit call number wrapped: words of 2^28 calls ago would look current
+        HIPCHK(c, hipDeviceSynchronize());
+        for (auto& slot : c->tw) for (auto& t : slot) if (t.lookback.p) HIPCHK(c, hipMemset(t.lookback.p, 0, t.lookback.cap));
+    }
     X.epoch = c->lb_epoch + 1;
     return GZ_OK;
 }
@@ -336,8 +350,12 @@ bool ids_fit_16(gz_ctx* c)
 
 int use_words_flags(gz_ctx* c, uint32_t flags)
 {
-    const char* ab = getenv("GZ_ABLATE");       // timing diagnostics only: results are wrong when set
+#ifdef GZ_DIAG
+    const char* ab = getenv("GZ_ABLATE");       // timing diagnostics only (diagnostic builds): results are wrong when set
     const int ablate = (ab && !c->building_words) ? atoi(ab) : 0;
+#else
+    const int ablate = 0;
+#endif
     const int use_words = (c->dev.words0 != nullptr && !(flags & GZ_NO_WORD_TABLE) && !c->no_words_env) ? 1 : 0;
     return use_words | (ablate << 8);
 }
@@ -368,7 +386,9 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
     int rc;
     if (!n_real) { rc = ensure(c, c->w_nreal, (size_t)(n_docs + 1) * 4); if (rc) return rc; n_real = (int32_t*)c->w_nreal.p; }
     gz_ctx::Pending& p = c->pend;
+    const bool chained = p.active;                             // (still pending: this call goes behind it on the stream)
     p = gz_ctx::Pending();
+    p.chained = chained;
     p.timing = (flags & GZ_TIMING) != 0;
 
     // Sub-batches: contiguous document ranges (dense layouts of large batches only).  Their byte positions are the
@@ -875,6 +895,7 @@ static int encode_host_locked(gz_ctx* c, const uint8_t* text, const int64_t* tex
         // copies down and two synchronisations.  Ragged outputs come down at their bound and are cut on the host.
         auto up16 = [](size_t v) { return (v + 15) & ~(size_t)15; };
         const int64_t tbs = text_off[n_docs] - text_off[0], pbs = is_pair ? pair_off[n_docs] - pair_off[0] : 0;
+        if ((tbs > 0 && !text) || (pbs > 0 && !pair)) return fail(c, GZ_E_INVALID, "text is NULL but the offsets are not empty");
         const size_t off_b = (size_t)(n_docs + 1) * 8;
         const size_t in_text = up16(off_b), in_poff = up16(in_text + (size_t)tbs + 16), in_pair = up16(in_poff + (is_pair ? off_b : 0));
         const size_t in_b = up16(in_pair + (size_t)pbs + 16);
@@ -1025,9 +1046,10 @@ int gz_host_alloc(gz_ctx* c, size_t bytes, void** ptr)
 
 int gz_host_free(gz_ctx* c, void* ptr)
 {
-    if (!c) return GZ_E_INVALID;
-    HIPCHK(c, hipSetDevice(c->device));
-    if (ptr) HIPCHK(c, hipHostFree(ptr));
+    // Independent of the context's state on purpose: a pinned block may outlive the context that allocated it (a numpy
+    // array finalized after Tokenize.close(), or at interpreter exit), so nothing of *c is touched; c may be NULL.
+    (void)c;
+    if (ptr && hipHostFree(ptr) != hipSuccess) return GZ_E_HIP;
     return GZ_OK;
 }
 
@@ -1111,8 +1133,11 @@ int gz_encode_batch_csr(gz_ctx* c, const uint8_t* text, const int64_t* text_off,
         A.raw = nullptr; A.n_real = (int32_t*)c->w_csr_nreal.p + lo;
         A.docs_per_wave = GZ_MAX_DOCS_PER_WAVE;
         HIPCHK(c, hipStreamWaitEvent(s, c->ev_in[k], 0));
-        if ((rc = setup_text(c, c->tw[k & 1][0], c->w_tiny[k & 7][0], d_text + text_off[lo], d_off + lo, text_off[hi] - text_off[lo], A.n_docs, s, A.X[0])))
+        if ((rc = setup_text(c, c->tw[k & 1][0], c->w_tiny[k & 7][0], d_text + text_off[lo], d_off + lo, text_off[hi] - text_off[lo], A.n_docs, s, A.X[0]))) {
+            // copies from / to the caller's buffers are in flight: let them finish before the caller gets its buffers back
+            hipStreamSynchronize(c->s_in); hipStreamSynchronize(s); hipStreamSynchronize(c->s_out);
             return rc;
+        }
         gz_launch_pipeline_text(T, c->dev, A.X[0], A.n_docs, use_words, (int32_t*)c->w_flags.p + 3, s, c->side, c->ev_sf[k & 1][0], c->ev_sj[k & 1][0]);
         gz_launch_assemble(T, A, s);
         uint32_t* off32 = (uint32_t*)c->w_csr_off32.p;
@@ -1140,6 +1165,9 @@ int gz_encode_batch_csr(gz_ctx* c, const uint8_t* text, const int64_t* text_off,
     HIPCHK(c, hipStreamSynchronize(c->s_out));
     HIPCHK(c, hipStreamSynchronize(s));
     *total_out = total;
+    // a look-back time-out in any sub-batch (sub-batches of 32 MB are exactly the size that takes the chained scan)
+    HIPCHK(c, hipMemcpy(c->h_flags, c->w_flags.p, 8, hipMemcpyDeviceToHost));
+    if (c->h_flags[0]) return fail(c, GZ_E_HIP, "internal: a chained scan (gz_scan32m_kernel look-back) timed out");
     if (ret) return fail(c, ret, "the batch has %lld real entries, capacity is %lld", (long long)total, (long long)capacity);
     return GZ_OK;
 }

@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgenz_tokenize_hip.so")
+# (GZ_LIBRARY: another build of the same library -- the diagnostic build of `make diag` in the tests)
+LIB_PATH = os.environ.get("GZ_LIBRARY") or os.path.join(_HERE, "libgenz_tokenize_hip.so")
 
 GZ_OK, GZ_E_INVALID, GZ_E_UTF8, GZ_E_HIP, GZ_E_NOTABLES = 0, -1, -2, -3, -4
 GZ_E_CAPACITY, GZ_E_LIMIT, GZ_E_NOMEM, GZ_E_RCCL, GZ_E_NODEVICE = -5, -6, -7, -8, -9
@@ -246,10 +247,11 @@ class Context:
         p = C.c_void_p()
         self._check(self.lib.gz_host_alloc(self.handle, max(n * dtype.itemsize, 1), C.byref(p)))
         buf = (C.c_char * max(n * dtype.itemsize, 1)).from_address(p.value)
-        lib, handle, addr = self.lib, self.handle, p.value
+        lib, addr = self.lib, p.value
         import weakref
         arr = np.frombuffer(buf, dtype=dtype, count=n).reshape(shape)
-        weakref.finalize(buf, lambda: lib.gz_host_free(handle, C.c_void_p(addr)))
+        # (gz_host_free does not look at the context: the array may well outlive it -- close(), interpreter exit)
+        weakref.finalize(buf, lambda: lib.gz_host_free(None, C.c_void_p(addr)))
         return arr
 
     def encode_csr(self, text: np.ndarray, text_off: np.ndarray, max_len: int, bits: int = 16, extra_flags: int = 0,

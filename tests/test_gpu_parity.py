@@ -626,6 +626,83 @@ def test_rccl_gather_two_ranks(tmp_path):
         assert (tmp_path / ("verdict_%d" % r)).read_text() == "ok"
 
 
+def test_pinned_array_outlives_its_context():
+    """A pinned array (gz_host_alloc) dropped AFTER its context was closed: gz_host_free must not touch the freed context."""
+    import gc
+    from genz_tokenize import Tokenize
+    t2 = Tokenize()
+    t2._sync_tables()
+    arr = t2._ctx.pinned_empty(1 << 20, np.uint8)
+    arr[:] = 7
+    t2._ctx.close()
+    assert int(arr[12345]) == 7                       # still mapped
+    del arr
+    gc.collect()                                       # the finalizer runs now, on a context that no longer exists
+
+
+def test_null_text_with_offsets_is_an_error_not_a_crash(tok):
+    import ctypes as C
+    from genz_tokenize import _native
+    tok._sync_tables()
+    ctx = tok._ctx
+    off = np.array([0, 5, 9], dtype=np.int64)
+    ids = np.zeros(64, dtype=np.int32); mask = np.zeros(64, dtype=np.int32)
+    rc = ctx.lib.gz_encode_batch(ctx.handle, None, off.ctypes.data_as(C.c_void_p), None, None, 2, 8,
+                                 _native.GZ_PADDING | _native.GZ_TRUNCATION, 64, ids.ctypes.data_as(C.c_void_p),
+                                 mask.ctypes.data_as(C.c_void_p), None, None, None, None, None, None)
+    assert rc == -1 and b"NULL" in ctx.lib.gz_last_error(ctx.handle)
+
+
+def test_scan_time_out_surfaces_from_every_host_path(tmp_path):
+    """A look-back time-out of the chained scan (forced in the diagnostic build: gz_diag_set(1, -1)) must come back as an
+    error from the CSR path and from a CHAIN of dense device calls -- also when the call that timed out is not the last
+    one of the chain."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["make", "-C", os.path.join(root, "genz-tokenize_amd", "csrc"), "diag"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    child = r"""
+import os, sys, ctypes as C
+import numpy as np
+root = %r
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "genz-tokenize_amd"))
+import corpus
+from genz_tokenize import Tokenize, _native
+tok = Tokenize(); tok._sync_tables(); ctx = tok._ctx
+text, offs, L = corpus.config_corpus(3, n_docs=60000)           # (GZ_SCAN_MULTI=0: every block-count scan is the chained kernel)
+offs = np.ascontiguousarray(offs, dtype=np.int64)
+toks, nr = ctx.encode_csr(text, offs, L, 16)                    # healthy first
+n_tok = len(toks)
+assert ctx.lib.gz_diag_set(1, -1) == 0                          # every look-back "times out" from now on
+try:
+    ctx.encode_csr(text, offs, L, 16)
+    print("FAIL: no error from the CSR path"); sys.exit(1)
+except _native.GzError as e:
+    assert "timed out" in str(e), str(e)
+# a chain of dense device calls: the FIRST one times out, the second runs healthy; the chain's close must still report it
+n = len(offs) - 1
+d_text = ctx.alloc(len(text) + 64); ctx.h2d(d_text, text)
+d_off = ctx.alloc(8 * (n + 1)); ctx.h2d(d_off, offs)
+d_ids = ctx.alloc(4 * n * L); d_mask = ctx.alloc(4 * n * L); d_nr = ctx.alloc(4 * n)
+flags = _native.GZ_PADDING | _native.GZ_TRUNCATION
+ctx.encode_device(d_text, d_off, 0, 0, n, L, flags, n * L, d_ids, d_mask, d_n_real=d_nr, h_text_off=offs)
+assert ctx.lib.gz_diag_set(1, 1 << 21) == 0
+ctx.encode_device(d_text, d_off, 0, 0, n, L, flags, n * L, d_ids, d_mask, d_n_real=d_nr, h_text_off=offs)
+try:
+    ctx.sync()
+    print("FAIL: the chain's time-out was lost"); sys.exit(1)
+except _native.GzError as e:
+    assert "timed out" in str(e), str(e)
+toks2, _ = ctx.encode_csr(text, offs, L, 16)                    # and the context works again afterwards
+assert len(toks2) == n_tok and np.array_equal(toks2, toks)
+print("ok")
+""" % root
+    env = dict(os.environ, GZ_LIBRARY=os.path.join(root, "build_ab", "libgz_diag.so"), GZ_SCAN_MULTI="0")
+    r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-2000:], r.stderr[-2000:])
+
+
 @pytest.mark.parametrize("world", [2, 4])
 def test_bench_multirank_exchange_on_one_gpu_over_gloo(world):
     """The N > 1 code of bench.py -- shard ownership, compact_rows16, exchange_select, per-round totals / block offsets,
