@@ -144,6 +144,7 @@ struct gz_ctx {
     uint32_t* h_tot = nullptr;           // pinned: compact size of every sub-batch
     uint8_t* h_stage = nullptr; size_t h_stage_cap = 0;      // pinned staging of small host calls (one copy in, one copy out)
     DBuf w_stage;
+    int cache_status = 0;                // of the last gz_load_tables: 0 no cache, 1 hit, 2 miss (written), 3 a file was refused (rebuilt)
     bool building_words = false;         // the whole-word table is being built: ignore diagnostics
     bool no_words_env = false;           // GZ_WORD_TABLE=0 in the environment
 };
@@ -515,11 +516,14 @@ static int encode_host_locked(gz_ctx* c, const uint8_t* text, const int64_t* tex
                     int32_t* input_ids, int32_t* attention_mask, int32_t* token_type_ids, int32_t* sequence_id,
                     int64_t* row_off, int32_t* pair_len, int32_t* n_real, int32_t* status);
 
+#include "gz_cache.inc"
+
 // Whole-word table.  Candidates are the merge-closure symbols that end a word (".....</w>", <= 16 bytes without the
 // marker).  Each candidate is tokenized BY THE GPU MERGE PATH ITSELF (one tiny document per word, table disabled);
 // a word whose result is exactly [bos, id, eos] is recorded as word -> id.  Nothing is computed on the CPU.
-static int build_word_table(gz_ctx* c)
+static int build_word_table(gz_ctx* c, WordImages& W)
 {
+    W = WordImages();
     GzHostTables& H = c->host;
     std::vector<uint8_t> text;
     std::vector<int64_t> off(1, 0);
@@ -572,16 +576,13 @@ static int build_word_table(gz_ctx* c)
     {
         size_t slots0 = 16;
         while (slots0 < gz_tab_slack() * found0.size()) slots0 <<= 1;
-        std::vector<GzWordSlot0> tab0(slots0, GzWordSlot0{0, 0, 0});
+        std::vector<GzWordSlot0>& tab0 = W.tab0;
+        tab0.assign(slots0, GzWordSlot0{0, 0, 0});
         for (const GzWordSlot0& e : found0) {
             size_t h = gz_word_hash0(e.lo, e.hi, e.meta & 15u) & (slots0 - 1);
             while (tab0[h].meta != 0) h = (h + 1) & (slots0 - 1);
             tab0[h] = e;
         }
-        if ((rc = upload(c, c->t_words0, tab0))) return rc;
-        HIPCHK(c, hipStreamSynchronize(c->stream));          // (tab0 dies at the end of this block)
-        c->dev.words0 = (const GzWordSlot0*)c->t_words0.p;
-        c->dev.word0_mask = (uint32_t)slots0 - 1;
     }
     {
         // the words of <= 16 bytes, perfectly hashed (the big pipeline's word kernel: one line per probe, gz_common.h)
@@ -591,15 +592,10 @@ static int build_word_table(gz_ctx* c)
             const GzWordSlot1& e = (*static_cast<const std::vector<GzWordSlot1>*>(ctx))[i];
             return gz_word1_ha(e.lo, e.hi, e.meta & 31u, k1, k2);
         };
-        GzPhHost ph;
+        GzPhHost& ph = W.ph;
         gz_ph_build(found1.size(), ha, &found1, hb.data(), ph, slot_of);
-        std::vector<GzWordSlot1> tabp(ph.slots, GzWordSlot1{0, 0, 0, {0, 0, 0}});
-        for (size_t i = 0; i < found1.size(); ++i) tabp[slot_of[i]] = found1[i];
-        if ((rc = upload(c, c->t_words0p, tabp)) || (rc = upload(c, c->t_word0_disp, ph.disp))) return rc;
-        HIPCHK(c, hipStreamSynchronize(c->stream));          // (the vectors die at the end of this block)
-        c->dev.words0p = (const GzWordSlot1*)c->t_words0p.p;
-        c->dev.word0_ph = GzPh{(const uint16_t*)c->t_word0_disp.p, ph.nbuckets, ph.bshift, ph.sshift, ph.slots - 1, ph.k1, ph.k2};
-        c->dev.word0_ovf = ph.n_overflow;
+        W.tabp.assign(ph.slots, GzWordSlot1{0, 0, 0, {0, 0, 0}});
+        for (size_t i = 0; i < found1.size(); ++i) W.tabp[slot_of[i]] = found1[i];
         // hot set: the words the vocab file counts most often (no counts: the file's order), direct-mapped by the top bits of ha
         std::unordered_map<std::string, uint64_t> weight;
         {
@@ -615,35 +611,51 @@ static int build_word_table(gz_ctx* c)
             order[i] = {it == weight.end() ? 0 : it->second, (uint32_t)i};
         }
         std::sort(order.begin(), order.end(), [](const std::pair<uint64_t, uint32_t>& x, const std::pair<uint64_t, uint32_t>& y) { return x.first != y.first ? x.first > y.first : x.second < y.second; });
-        std::vector<GzWordSlot0> hot(GZ_WORD_HOT_SLOTS, GzWordSlot0{0, 0, 0});
+        std::vector<GzWordSlot0>& hot = W.hot;
+        hot.assign(GZ_WORD_HOT_SLOTS, GzWordSlot0{0, 0, 0});
         for (const auto& o : order) {
             const GzWordSlot0& e = found0[o.second];
             GzWordSlot0& h = hot[gz_word1_ha(e.lo, e.hi, e.meta & 15u, ph.k1, ph.k2) >> GZ_WORD_HOT_SHIFT];
             if (h.meta == 0) h = e;
         }
-        if ((rc = upload(c, c->t_word_hot, hot))) return rc;
-        HIPCHK(c, hipStreamSynchronize(c->stream));
-        c->dev.word_hot = (const GzWordSlot0*)c->t_word_hot.p;
     }
     if (!found2.empty()) {
         size_t slots2 = 16;
         while (slots2 < gz_tab_slack() * found2.size()) slots2 <<= 1;
-        std::vector<GzWordSlot2> tab2(slots2, GzWordSlot2{{0, 0, 0, 0}, 0, 0, {0, 0, 0, 0, 0, 0}});
+        std::vector<GzWordSlot2>& tab2 = W.tab2;
+        tab2.assign(slots2, GzWordSlot2{{0, 0, 0, 0}, 0, 0, {0, 0, 0, 0, 0, 0}});
         for (const GzWordSlot2& e : found2) {
             size_t h = gz_word_hash2(e.k, e.len) & (slots2 - 1);
             while (tab2[h].len != 0) h = (h + 1) & (slots2 - 1);
             tab2[h] = e;
         }
-        if ((rc = upload(c, c->t_words2, tab2))) return rc;
-        HIPCHK(c, hipStreamSynchronize(c->stream));          // (tab2 dies at the end of this block)
-        c->dev.words2 = (const GzWordSlot2*)c->t_words2.p;
-        c->dev.word2_mask = (uint32_t)slots2 - 1;
     }
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipMemcpy(c->t_struct.p, &c->dev, sizeof(GzDeviceTables), hipMemcpyHostToDevice));
-    c->n_words = (int64_t)(found0.size() + found2.size());
+    W.n_words = (int64_t)(found0.size() + found2.size());
     return GZ_OK;
 }
+
+// The whole-word tables onto the device (built just now, or read from the cache) and into the table descriptor.
+static int install_word_tables(gz_ctx* c, const WordImages& W)
+{
+    int rc;
+    if (W.tabp.empty()) return GZ_OK;
+    if ((rc = upload(c, c->t_words0, W.tab0)) || (rc = upload(c, c->t_words0p, W.tabp)) || (rc = upload(c, c->t_word0_disp, W.ph.disp)) ||
+        (rc = upload(c, c->t_word_hot, W.hot)))
+        return rc;
+    if (!W.tab2.empty() && (rc = upload(c, c->t_words2, W.tab2))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));                  // (the images may die once this returns)
+    GzDeviceTables& D = c->dev;
+    D.words0 = (const GzWordSlot0*)c->t_words0.p; D.word0_mask = (uint32_t)W.tab0.size() - 1;
+    D.words0p = (const GzWordSlot1*)c->t_words0p.p;
+    D.word0_ph = GzPh{(const uint16_t*)c->t_word0_disp.p, W.ph.nbuckets, W.ph.bshift, W.ph.sshift, W.ph.slots - 1, W.ph.k1, W.ph.k2};
+    D.word0_ovf = W.ph.n_overflow;
+    D.word_hot = (const GzWordSlot0*)c->t_word_hot.p;
+    if (!W.tab2.empty()) { D.words2 = (const GzWordSlot2*)c->t_words2.p; D.word2_mask = (uint32_t)W.tab2.size() - 1; }
+    HIPCHK(c, hipMemcpy(c->t_struct.p, &c->dev, sizeof(GzDeviceTables), hipMemcpyHostToDevice));
+    c->n_words = W.n_words;
+    return GZ_OK;
+}
+
 
 // =================================================================================================================
 extern "C" {
@@ -743,10 +755,26 @@ int gz_load_tables(gz_ctx* c, const uint8_t* vocab, size_t vocab_len, const uint
     HIPCHK(c, hipSetDevice(c->device));
     if (c->pend.active) { int rc = sync_locked(c); if (rc) return rc; }
     c->have_tables = false;
-    int rc;
+    int rc = GZ_OK;
+    static const uint8_t empty = 0;
+    if (!vocab) vocab = &empty;
+    if (!bpe) bpe = &empty;
+    // ---- the table cache: the finished images of these very files, if a verified copy exists (gz_cache.inc)
+    WordImages W;
+    uint8_t key[32];
+    const std::string cdir = cache_dir();
+    std::string cpath;
+    bool hit = false;
+    c->cache_status = 0;
     try {
-        static const uint8_t empty = 0;
-        rc = gz_build_tables(vocab ? vocab : &empty, vocab_len, bpe ? bpe : &empty, bpe_len, specials, c->host, c->err);
+        if (!cdir.empty()) {
+            cache_key(vocab, vocab_len, bpe, bpe_len, specials, key);
+            cpath = cache_file(cdir, key);
+            const int got = cache_read(cpath, key, c->host, W);
+            hit = got == 1;
+            c->cache_status = got == 1 ? 1 : got < 0 ? 3 : 2;      // 1 hit, 2 miss, 3 a file was there and was refused
+        }
+        if (!hit) rc = gz_build_tables(vocab, vocab_len, bpe, bpe_len, specials, c->host, c->err);
     } catch (const std::bad_alloc&) {
         return fail(c, GZ_E_NOMEM, "out of host memory while building tables");
     } catch (...) {
@@ -782,8 +810,69 @@ int gz_load_tables(gz_ctx* c, const uint8_t* vocab, size_t vocab_len, const uint
     if ((rc = ensure(c, c->t_struct, sizeof(GzDeviceTables)))) return rc;
     HIPCHK(c, hipMemcpy(c->t_struct.p, &c->dev, sizeof(GzDeviceTables), hipMemcpyHostToDevice));
     c->have_tables = true;
-    rc = build_word_table(c);
+    if (!hit) {
+        rc = build_word_table(c, W);                             // (runs the GPU merge path over every candidate word)
+        if (rc) { c->have_tables = false; return rc; }
+    }
+    rc = install_word_tables(c, W);
     if (rc) { c->have_tables = false; return rc; }
+    if (!hit && !cpath.empty()) {
+        try { cache_write(cdir, cpath, key, c->host, W); } catch (...) { /* a cache that cannot be written is only a slower start */ }
+    }
+    return GZ_OK;
+}
+
+int gz_table_cache_status(gz_ctx* c)
+{
+    return c ? c->cache_status : GZ_E_INVALID;
+}
+
+// SHA-256 over every device-resident table image and the descriptor's scalar fields: two contexts whose tables were built
+// from the same files -- one by the builder, one from the cache -- must give the same digest.
+int gz_table_digest(gz_ctx* c, uint8_t out[32])
+{
+    if (!c || !out) return GZ_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->have_tables) return fail(c, GZ_E_NOTABLES, "gz_load_tables has not been called");
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->pend.active) { int rc = sync_locked(c); if (rc) return rc; }
+    Sha256 sha;
+    std::vector<uint8_t> buf;
+    auto add = [&](const void* dptr, size_t bytes) -> int {
+        const uint64_t n = bytes;
+        sha.update(&n, 8);
+        if (!bytes) return GZ_OK;
+        buf.resize(bytes);
+        HIPCHK(c, hipMemcpy(buf.data(), dptr, bytes, hipMemcpyDeviceToHost));
+        sha.update(buf.data(), bytes);
+        return GZ_OK;
+    };
+    const GzDeviceTables& D = c->dev;
+    const GzHostTables& H = c->host;
+    int rc;
+    if ((rc = add(D.pair_tab, ((size_t)D.pair_mask + 1) * sizeof(GzPairSlot))) || (rc = add(D.merges, (size_t)D.n_ranks * sizeof(GzMergeInfo))) ||
+        (rc = add(D.sym_ids, (size_t)D.n_symbols * sizeof(GzSymIds))) || (rc = add(D.bmp, 65536 * sizeof(GzCpSyms))) ||
+        (rc = add(D.astral, D.astral ? ((size_t)D.astral_mask + 1) * sizeof(GzAstral) : 0)) ||
+        (rc = add(D.pair8, ((size_t)D.pair_ph.mask + 1) * sizeof(GzPair8))) || (rc = add(D.pair_ph.disp, (size_t)D.pair_ph.nbuckets * 2)) ||
+        (rc = add(D.pair_hot, GZ_PAIR_HOT_SLOTS * sizeof(GzPair8))) ||
+        (rc = add(D.words0, D.words0 ? ((size_t)D.word0_mask + 1) * sizeof(GzWordSlot0) : 0)) ||
+        (rc = add(D.words2, D.words2 ? ((size_t)D.word2_mask + 1) * sizeof(GzWordSlot2) : 0)) ||
+        (rc = add(D.words0p, D.words0p ? ((size_t)D.word0_ph.mask + 1) * sizeof(GzWordSlot1) : 0)) ||
+        (rc = add(D.word0_ph.disp, D.words0p ? (size_t)D.word0_ph.nbuckets * 2 : 0)) ||
+        (rc = add(D.word_hot, D.word_hot ? GZ_WORD_HOT_SLOTS * sizeof(GzWordSlot0) : 0)))
+        return rc;
+    const uint32_t scal[] = {D.pair_mask, D.pair_shift, D.n_ranks, D.n_symbols, D.astral_mask, (uint32_t)D.pad_id, (uint32_t)D.bos_id, (uint32_t)D.eos_id,
+                             (uint32_t)D.unk_id, D.word0_mask, D.word2_mask, D.pair_ph.nbuckets, D.pair_ph.bshift, D.pair_ph.sshift, D.pair_ph.mask,
+                             D.pair_ph.k1, D.pair_ph.k2, D.word0_ph.nbuckets, D.word0_ph.bshift, D.word0_ph.sshift, D.word0_ph.mask, D.word0_ph.k1,
+                             D.word0_ph.k2, D.pair_ovf, D.word0_ovf, D.pair_hot_shift, D.word_hot_shift};
+    sha.update(scal, sizeof scal);
+    // the host side of the tables (what the Python surface reads back)
+    for (const std::string& w : H.enc_words) { const uint32_t l = (uint32_t)w.size(); sha.update(&l, 4); sha.update(w.data(), l); }
+    if (!H.enc_ids.empty()) sha.update(H.enc_ids.data(), H.enc_ids.size() * 4);
+    for (const std::string& w : H.rank_keys) { const uint32_t l = (uint32_t)w.size(); sha.update(&l, 4); sha.update(w.data(), l); }
+    if (!H.rank_vals.empty()) sha.update(H.rank_vals.data(), H.rank_vals.size() * 4);
+    for (const std::string& w : H.symbols) { const uint32_t l = (uint32_t)w.size(); sha.update(&l, 4); sha.update(w.data(), l); }
+    sha.final(out);
     return GZ_OK;
 }
 

@@ -23,7 +23,7 @@ GZ_PP_HTML, GZ_PP_UNICODE, GZ_PP_PUNCT, GZ_PP_EMOJI, GZ_PP_URL = 1, 2, 3, 4, 5
 
 # every symbol include/genz_tokenize.h declares (tests/test_abi.py checks the export list against the header)
 SYMBOLS = [
-    "gz_version", "gz_create", "gz_destroy", "gz_last_error", "gz_load_tables", "gz_table_info",
+    "gz_version", "gz_create", "gz_destroy", "gz_last_error", "gz_load_tables", "gz_table_info", "gz_table_cache_status", "gz_table_digest",
     "gz_vocab_entry", "gz_merge_entry", "gz_encode_batch", "gz_encode_batch_csr", "gz_host_alloc", "gz_host_free", "gz_encode_batch_device", "gz_encode_batch_device_h", "gz_sync",
     "gz_word_token_counts", "gz_bpe_word", "gz_symbol_utf8", "gz_device_alloc", "gz_device_free", "gz_memcpy_h2d", "gz_memcpy_d2h",
     "gz_timing", "gz_timing_history", "gz_decoder_snapshot", "gz_decode_batch", "gz_decode_batch_device", "gz_preprocess_batch",
@@ -59,6 +59,8 @@ def load_library():
     L.gz_last_error.argtypes = [vp]; L.gz_last_error.restype = C.c_char_p
     L.gz_load_tables.argtypes = [vp, vp, sz, vp, sz, P(C.c_char_p)]
     L.gz_table_info.argtypes = [vp, P(i32), P(i32), P(i32), P(i32)]
+    L.gz_table_cache_status.argtypes = [vp]
+    L.gz_table_digest.argtypes = [vp, vp]
     L.gz_vocab_entry.argtypes = [vp, i64, P(vp), P(i32), P(i32)]
     L.gz_merge_entry.argtypes = [vp, i64, P(vp), P(i32), P(i32), P(i32)]
     enc = [vp, vp, vp, vp, vp, i64, i32, u32, i64, vp, vp, vp, vp, vp, vp, vp, vp]
@@ -159,6 +161,16 @@ class Context:
         bb = C.create_string_buffer(bpe, len(bpe)) if bpe else None
         self._check(self.lib.gz_load_tables(self.handle, C.cast(vb, C.c_void_p) if vb else None, len(vocab),
                                             C.cast(bb, C.c_void_p) if bb else None, len(bpe), arr))
+
+    def table_cache_status(self) -> int:
+        """What the last load_tables did with the table cache: 0 no cache, 1 hit, 2 miss (written), 3 a file was refused."""
+        return int(self.lib.gz_table_cache_status(self.handle))
+
+    def table_digest(self) -> bytes:
+        """SHA-256 over the device-resident table images and the dictionaries (gz_table_digest)."""
+        out = (C.c_uint8 * 32)()
+        self._check(self.lib.gz_table_digest(self.handle, out))
+        return bytes(out)
 
     def table_info(self):
         vs, nr, ns = C.c_int32(), C.c_int32(), C.c_int32()

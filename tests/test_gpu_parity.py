@@ -626,6 +626,60 @@ def test_rccl_gather_two_ranks(tmp_path):
         assert (tmp_path / ("verdict_%d" % r)).read_text() == "ok"
 
 
+def test_table_cache_hit_is_identical_and_bad_files_are_refused(tmp_path):
+    """gz_load_tables behind the table cache: a second load of the same files is a HIT whose device tables are byte-identical
+    to the built ones (gz_table_digest) and which tokenizes like them; a corrupted file, a truncated file and a file of
+    another layout version are refused (rebuilt, rewritten), never trusted; other files get another key."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = r"""
+import glob, os, sys, time
+root = %r
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "genz-tokenize_amd"))
+import numpy as np
+import corpus
+from genz_tokenize import Tokenize
+cdir = os.environ["GZ_TABLE_CACHE"]
+def load(**kw):
+    t0 = time.perf_counter()
+    t = Tokenize(**kw); t._sync_tables()
+    return t, time.perf_counter() - t0
+a, ta = load()
+assert a._ctx.table_cache_status() == 2, a._ctx.table_cache_status()            # miss: built, written
+files = glob.glob(os.path.join(cdir, "*.gztab"))
+assert len(files) == 1
+b, tb = load()
+assert b._ctx.table_cache_status() == 1                                          # hit
+assert a._ctx.table_digest() == b._ctx.table_digest()
+assert a.encoder == b.encoder and a.bpe_ranks == b.bpe_ranks
+text, offs, L = corpus.config_corpus(3, n_docs=3000, seed=21)
+ra, rb = a.encode_packed(text, offs, max_len=64), b.encode_packed(text, offs, max_len=64)
+assert np.array_equal(ra["input_ids"], rb["input_ids"]) and np.array_equal(ra["attention_mask"], rb["attention_mask"])
+assert b("sinh_viên công_nghệ", "hello", max_len=10)["input_ids"] == [1, 770, 1444, 2, 2, 30469, 2, 0, 0, 0]
+good = open(files[0], "rb").read()
+def damaged(blob):
+    open(files[0], "wb").write(blob)
+    t, _ = load()
+    st = t._ctx.table_cache_status()
+    assert t._ctx.table_digest() == a._ctx.table_digest()
+    assert open(files[0], "rb").read() == good                                   # rewritten from the rebuilt tables
+    return st
+flip = bytearray(good); flip[len(flip) // 2] ^= 0x40
+assert damaged(bytes(flip)) == 3                                                 # one flipped bit in the payload
+assert damaged(good[:len(good) - 100]) == 3                                      # truncated
+assert damaged(good + b"x") == 3                                                 # trailing bytes
+stale = bytearray(good); stale[4] ^= 0x01
+assert damaged(bytes(stale)) == 3                                                # another layout version
+c2, _ = load(unk_token="<unknown>")                                              # other specials: another key, another file
+assert c2._ctx.table_cache_status() == 2 and len(glob.glob(os.path.join(cdir, "*.gztab"))) == 2
+print("ok build %%.3f s, cached %%.3f s" %% (ta, tb))
+""" % root
+    env = dict(os.environ, GZ_TABLE_CACHE=str(tmp_path / "cache"))
+    r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1].startswith("ok"), (r.stdout[-2000:], r.stderr[-3000:])
+
+
 def test_pinned_array_outlives_its_context():
     """A pinned array (gz_host_alloc) dropped AFTER its context was closed: gz_host_free must not touch the freed context."""
     import gc

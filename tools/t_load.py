@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
-"""Construction time of the drop-in (the reference takes 0.27 s for Tokenize(), twice that for fromFile)."""
+"""Construction time of the drop-in (the reference takes 0.27 s for Tokenize(), twice that for fromFile: tokenize.py:39-42,
+:261-267), without the table cache, on a cache miss and on a cache hit (gz_cache.inc)."""
 import os
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,14 +11,29 @@ sys.path.insert(0, os.path.join(ROOT, "genz-tokenize_amd"))
 t0 = time.perf_counter()
 from genz_tokenize import Tokenize  # noqa: E402
 t1 = time.perf_counter()
-tok = Tokenize(); tok._sync_tables()
-t2 = time.perf_counter()
-tok2 = Tokenize(); tok2._sync_tables()
-t3 = time.perf_counter()
 d = os.path.join(ROOT, "genz-tokenize_amd", "genz_tokenize", "data")
-tok3 = Tokenize.fromFile(os.path.join(d, "vocab.txt"), os.path.join(d, "bpe.codes")); tok3._sync_tables()
-t4 = time.perf_counter()
-_ = tok3.decoder
-t5 = time.perf_counter()
-print("import %.3f s; first Tokenize() + table build %.3f s (HIP runtime start-up included); second %.3f s; fromFile %.3f s; "
-      "first .decoder access %.3f s" % (t1 - t0, t2 - t1, t3 - t2, t4 - t3, t5 - t4))
+
+
+def timed(make):
+    a = time.perf_counter()
+    tok = make(); tok._sync_tables()
+    return tok, time.perf_counter() - a
+
+
+os.environ["GZ_TABLE_CACHE"] = "off"
+tok, first = timed(Tokenize)
+print("import %.3f s; first Tokenize() %.3f s (HIP runtime start-up included)" % (t1 - t0, first))
+_, nocache = timed(Tokenize)
+_, nocache_ff = timed(lambda: Tokenize.fromFile(os.path.join(d, "vocab.txt"), os.path.join(d, "bpe.codes")))
+print("no cache:   Tokenize() %.1f ms   fromFile %.1f ms" % (nocache * 1e3, nocache_ff * 1e3))
+os.environ["GZ_TABLE_CACHE"] = tempfile.mkdtemp()
+m, miss = timed(Tokenize)
+h, hit = timed(Tokenize)
+h2, hit2 = timed(Tokenize)
+ff, hit_ff = timed(lambda: Tokenize.fromFile(os.path.join(d, "vocab.txt"), os.path.join(d, "bpe.codes")))
+print("cache miss: Tokenize() %.1f ms (status %d)" % (miss * 1e3, m._ctx.table_cache_status()))
+print("cache hit:  Tokenize() %.1f ms, %.1f ms (status %d)   fromFile %.1f ms (status %d)" % (
+    hit * 1e3, hit2 * 1e3, h._ctx.table_cache_status(), hit_ff * 1e3, ff._ctx.table_cache_status()))
+print("digests equal:", m._ctx.table_digest() == h._ctx.table_digest() == ff._ctx.table_digest())
+a = time.perf_counter(); _ = h.decoder; b = time.perf_counter()
+print("first .decoder access %.1f ms" % ((b - a) * 1e3))
