@@ -41,8 +41,8 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 N_SHARDS, SHARD_DOCS, SHARD_SEED0 = 8, 1_250_000, 100
-PIPELINE = ("gz_brk, gz_classify, gz_scan32, gz_docw0, gz_words, gz_scan32 (misses), gz_miss, gz_miss_wide, gz_long, "
-            "gz_rows1")
+PIPELINE = ("gz_brk, gz_classify, gz_scan32, gz_docw0, gz_words2, gz_scan32 (misses), gz_mpre, gz_miss2 || gz_miss_wide + gz_long "
+            "(side stream), gz_rows1")
 
 
 def kernel_source_sha16():
@@ -552,7 +552,8 @@ def main():
         for sh in shards:
             for q in [sh["d_text"], sh["d_off"]] + [x for st in sh["sets"] for x in (st["ids"], st["mask"], st["nreal"])]:
                 ctx.free(q)
-        sec = secondary(ctx, tok, flags, args, cfg2)
+        sec = {"headline_host_paths": headline_e2e(ctx, shards, L, int(total_tokens))}
+        sec.update(secondary(ctx, tok, flags, args, cfg2))
         sec.update(cpu)
 
     if rank == 0:
@@ -561,7 +562,7 @@ def main():
         in_b = shards[0]["in_bytes"] if m == 1 else float(np.mean([sh["in_bytes"] for sh in shards]))
         algo = _algo_bytes(in_b, n, L)
         achieved = algo / (k_ms * 1e-3) / 1e9
-        shard_traffic = _pmc_traffic("r02_pmc_traffic_shard.json")
+        shard_traffic = _pmc_traffic("r03_pmc_traffic_shard.json")
         out = {
             "metric": "UTF-8 MB/s tokenized (Tokenize.__call__ hot path: split + BPE + vocab lookup + pad/trunc + mask)",
             "value": round(total_bytes * args.steps / elapsed / 1e6, 2),
@@ -570,6 +571,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "value_is": "timing (i) of SURVEY.md 8(d): the whole job through the kernels, inputs resident in HBM when the clock starts, outputs left "
+                        "in HBM (wall clock over the steps, max over ranks).  The PCIe-inclusive rate of the same job -- timing (ii), host "
+                        "buffers in and out -- is headline_host_paths.MB_per_s; timing (iii), Python lists of str, is "
+                        "configs_2_roofline_run.timings.python_e2e_ms.",
             "dtype": "u8",                                          # bytes in, int32 ids out; integer / byte indexing only
             "data": "synthetic (unigram sampler over the bundled vocab.txt counts, corpus.py; shard s = seed %d + s; generated in %.1f s, untimed)" % (SHARD_SEED0, t_gen),
             "config": {"workload": "BASELINE configs[3]: ONE fixed job of %d mixed-length sentences (70%% 5-30 / 25%% 31-120 / 5%% 121-400 "
@@ -589,10 +594,13 @@ def main():
                          "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 5),
                          "traffic": shard_traffic["bytes_per_step"] if shard_traffic else None,
-                         "traffic_note": ("profiles/r02_pmc_traffic_shard.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over one "
+                         # the text is streamed twice with 16-byte-per-lane loads (classify, words), which FETCH_SIZE counts at half
+                         # their bytes on gfx950 (MI355X_MICROARCH.md, HBM): the corrected figure adds the uncounted half of both passes
+                         "traffic_corrected": int(shard_traffic["bytes_per_step"] + in_b) if shard_traffic else None,
+                         "traffic_note": ("profiles/r03_pmc_traffic_shard.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over one "
                                           "launch on shard 0 (1.25 M documents), same kernel sources (sha %s); reads of 16-B streams are "
                                           "half-counted on gfx950, not corrected" % kernel_source_sha16()) if shard_traffic else
-                                         "null: profiles/r02_pmc_traffic_shard.json is absent or was taken on other kernel sources",
+                                         "null: profiles/r03_pmc_traffic_shard.json is absent or was taken on other kernel sources",
                          "algorithmic_bytes_per_launch": int(algo),
                          "kernel_ms_avg": round(k_ms, 4), "launches_timed": len(kernel_ms),
                          "timed_with": "hipEvents on the library's stream around each launch of the pipeline, inside the timed region"},
@@ -616,6 +624,36 @@ def _pmc_traffic(name):
     return None
 
 
+def headline_e2e(ctx, shards, L, n_tok_expected):
+    """SURVEY.md 8(d) timing (ii) for the HEADLINE job (BASELINE configs[3], all 8 shards on this GPU): host buffers in, host
+    buffers out.  Every shard goes through gz_encode_batch_csr from pinned host memory: its text travels H2D in 32-MB
+    sub-batches under the kernels of the sub-batch before, and the rows' real entries (16-bit) + 4 bytes per document
+    travel back under the kernels of the sub-batch after.  The pinned buffers are allocated and filled before the clock starts."""
+    nmax = max(sh["n"] for sh in shards)
+    bmax = max(sh["in_bytes"] for sh in shards)
+    ptext = ctx.pinned_empty(bmax, np.uint8)
+    ptok = ctx.pinned_empty(min(nmax * L, bmax + 2 * nmax), np.uint16)
+    pnr = ctx.pinned_empty(nmax, np.int32)
+    times, tokens, pcie = [], 0, 0
+    for rep in range(2):                                         # (the first pass warms the workspace allocations up)
+        times, tokens, pcie = [], 0, 0
+        for sh in shards:
+            ptext[:sh["in_bytes"]] = sh["text"]
+            t_a = time.perf_counter()
+            toks, nr = ctx.encode_csr(ptext[:sh["in_bytes"]], sh["offs"], L, 16, tokens=ptok, n_real=pnr)
+            times.append(time.perf_counter() - t_a)
+            tokens += int(len(toks))
+            pcie += sh["in_bytes"] + 8 * (sh["n"] + 1) + int(toks.nbytes) + 4 * sh["n"]
+    total_b = sum(sh["in_bytes"] for sh in shards)
+    dt = sum(times)
+    del ptext, ptok, pnr
+    return {"what": "timing (ii) of SURVEY.md 8(d) for the headline job: the %d shards one after the other through gz_encode_batch_csr, pinned host "
+                    "text in, pinned host CSR rows (16-bit ids + row lengths) out; H2D, kernels and D2H of consecutive 32-MB sub-batches overlap "
+                    "on three streams" % len(shards),
+            "device_e2e_ms": round(dt * 1e3, 3), "MB_per_s": round(total_b / dt / 1e6, 1), "bytes_over_pcie": int(pcie),
+            "pcie_GB_per_s": round(pcie / dt / 1e9, 2), "tokens_match_headline": tokens == n_tok_expected}
+
+
 def secondary(ctx, tok, flags, args, cfg2):
     """Everything the N=1 line reports besides the headline: the configs[2] roofline run with its three timings, the
     merge-loop-only and OOV figures, configs[1], configs[4], the "next" rows, the CPU baseline."""
@@ -637,7 +675,7 @@ def secondary(ctx, tok, flags, args, cfg2):
     n_tok = int(mask.sum(dtype=np.int64))
     del ids, mask
     algo = _algo_bytes(R.in_bytes, R.n, L)
-    traffic = _pmc_traffic("r02_pmc_traffic.json")
+    traffic = _pmc_traffic("r03_pmc_traffic.json")
     # (ii) device end-to-end: host buffers in, host buffers out (PCIe both ways).  The library's host path for batches is
     # gz_encode_batch_csr: sub-batches, text H2D / kernels / D2H on three streams, and only the rows' real entries
     # (16-bit) + 4 bytes per document come back; the buffers are pinned (gz_host_alloc), as SURVEY.md 8(d) (ii) says.
@@ -683,9 +721,9 @@ def secondary(ctx, tok, flags, args, cfg2):
                      "frac": round(algo / k_ms / 1e6 / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_launch": int(algo),
                      "kernel_ms_avg": round(k_ms, 4),
                      "traffic": traffic["bytes_per_step"] if traffic else None,
-                     "traffic_source": "profiles/r02_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, summed over the "
+                     "traffic_source": "profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, summed over the "
                                        "launch's kernels; reads not corrected for the gfx950 half-count)" if traffic else
-                                       "none for this build (profiles/r02_pmc_traffic.json absent or taken on other kernel sources)"}}
+                                       "none for this build (profiles/r03_pmc_traffic.json absent or taken on other kernel sources)"}}
     # ---- the same step with the whole-word tables off: every word through the merge loop
     k2 = R.kernel_ms(flags | _native.GZ_NO_WORD_TABLE, reps=3)
     out["merge_loop_only"] = {"kernel_ms_avg": round(k2, 4), "MB_per_s_kernel": round(R.in_bytes / k2 / 1e3, 1)}

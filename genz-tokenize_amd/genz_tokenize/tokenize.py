@@ -17,7 +17,7 @@ from typing import Dict, List, Optional, Sequence
 
 import numpy as np
 
-from . import _native
+from . import _native, _packing
 from ._packing import pack as _pack            # list of str -> packed UTF-8 + offsets (C when built)
 
 _DATA = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
@@ -278,9 +278,49 @@ class Tokenize(object):
         document for which the single-call API raises ValueError."""
         if pair_texts is not None and len(pair_texts) != len(texts):
             raise ValueError("texts and pair_texts differ in length")
+        if (pair_texts is None and padding and truncation and max_len is not None and int(max_len) >= 1 and len(texts) >= 20000
+                and _packing._gz_pack is not None):
+            return self._encode_batch_large(texts, int(max_len), word_table)
         r = self._run(list(texts), None if pair_texts is None else list(pair_texts), max_len, padding, truncation,
                       word_table)
         return self._shape(r, len(texts))
+
+    def _encode_batch_large(self, texts, max_len, word_table):
+        """Large dense single-text batches: the strings are packed on threads (csrc/gz_pack.c), the packed text goes through
+        the CSR host path (only the text and the rows' real entries cross PCIe, in a pinned arena this object keeps), and the
+        dense [N, max_len] arrays the caller gets are filled from the CSR rows by host threads -- the same values as the
+        dense device path, without 2 * N * max_len * 4 bytes of mostly padding crossing PCIe into pageable memory."""
+        self._sync_tables()
+        tb, to = _pack(texts)
+        n = len(to) - 1
+        nbytes = int(to[-1]) if n else 0
+        sp = self._special_ids()
+        bits = 16 if self.vocab_size() <= 65536 and max(sp) < 65536 and min(sp) >= 0 else 32
+        ctx = self._ctx
+        arena = getattr(self, "_arena", None)
+        cap = max(min(n * max_len, nbytes + 2 * n), 1)
+        if arena is None or arena["text"].size < nbytes or arena["tok"].size * arena["tok"].itemsize < cap * 4 or arena["nr"].size < n:
+            arena = dict(text=ctx.pinned_empty(max(int(nbytes * 1.25), 1 << 20), np.uint8),
+                         tok=ctx.pinned_empty(max(int(cap * 1.25), 1 << 18), np.int32), nr=ctx.pinned_empty(max(int(n * 1.25), 1024), np.int32))
+            self._arena = arena
+        arena["text"][:nbytes] = tb
+        flags = 0 if word_table else _native.GZ_NO_WORD_TABLE
+        tokbuf = arena["tok"].view(np.uint16)[:2 * arena["tok"].size] if bits == 16 else arena["tok"]
+        try:
+            tokens, n_real = ctx.encode_csr(arena["text"][:nbytes], to, max_len, bits, flags, tokens=tokbuf, n_real=arena["nr"])
+        except _native.GzError as e:
+            if bits == 16 and e.code == _native.GZ_E_LIMIT:              # an id collision pushed an id past 65535
+                bits = 32
+                tokens, n_real = ctx.encode_csr(arena["text"][:nbytes], to, max_len, 32, flags, tokens=arena["tok"], n_real=arena["nr"])
+            else:
+                raise
+        row_off = np.zeros(n + 1, dtype=np.int64)
+        np.cumsum(n_real, out=row_off[1:])
+        ids = np.empty((n, max_len), dtype=np.int32)
+        mask = np.empty((n, max_len), dtype=np.int32)
+        _packing._gz_pack.expand(tokens, bits, n_real, row_off, max_len, int(sp[0]), ids, mask)
+        return dict(input_ids=ids, attention_mask=mask, row_off=np.arange(n + 1, dtype=np.int64) * max_len, n_real=np.array(n_real[:n]),
+                    status=np.zeros(n, dtype=np.int32), dense=True, max_len=max_len)
 
     def encode_packed(self, text_u8: np.ndarray, offsets: np.ndarray, pair_u8=None, pair_offsets=None,
                       max_len: Optional[int] = None, padding: bool = True, truncation: bool = True,

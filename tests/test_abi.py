@@ -76,3 +76,28 @@ def test_string_packer_matches_python_encoding():
     for bad in (["a"] * 8 + [3], ["a"] * 8 + [b"x"], ["a"] * 8 + [None]):
         with pytest.raises(TypeError, match="expected string or bytes-like object"):
             _packing.pack(bad)
+
+
+def test_host_expand_of_csr_rows_matches_numpy():
+    """csrc/gz_pack.c expand(): CSR rows -> dense [N, L] input_ids (padded with the pad id) + attention_mask = ids != pad,
+    on threads; against a plain numpy restatement (16- and 32-bit entries, empty rows, full rows, a real token equal to the pad id)."""
+    import numpy as np
+    _packing = pytest.importorskip("genz_tokenize._packing")
+    if _packing._gz_pack is None or not hasattr(_packing._gz_pack, "expand"):
+        pytest.skip("_gz_pack is not built (make -C genz-tokenize_amd/csrc pack)")
+    rng = np.random.default_rng(4)
+    for n, L, pad, bits in ((1, 4, 0, 16), (1000, 16, 0, 16), (30000, 32, 7, 32), (25000, 8, 3, 16)):
+        n_real = rng.integers(0, L + 1, size=n).astype(np.int32)
+        row = np.zeros(n + 1, dtype=np.int64); np.cumsum(n_real, out=row[1:])
+        toks = rng.integers(0, 60000, size=int(row[-1])).astype(np.uint16 if bits == 16 else np.int32)
+        if len(toks) > 5:
+            toks[::5] = pad                                                  # real tokens equal to the pad id: mask 0 there
+        ids = np.empty((n, L), dtype=np.int32); mask = np.empty((n, L), dtype=np.int32)
+        _packing._gz_pack.expand(toks, bits, n_real, row, L, pad, ids, mask)
+        want = np.full((n, L), pad, dtype=np.int32)
+        sel = np.arange(L)[None, :] < n_real[:, None]
+        want[sel] = toks.astype(np.int32)
+        assert np.array_equal(ids, want) and np.array_equal(mask, (want != pad).astype(np.int32))
+    with pytest.raises(ValueError):
+        _packing._gz_pack.expand(np.zeros(3, np.uint16), 16, np.array([2, 2], np.int32), np.array([0, 2, 4], np.int64), 4, 0,
+                                 np.empty((2, 4), np.int32), np.empty((2, 4), np.int32))       # fewer entries than the rows announce

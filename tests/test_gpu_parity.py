@@ -680,6 +680,25 @@ print("ok build %%.3f s, cached %%.3f s" %% (ta, tb))
     assert r.returncode == 0 and r.stdout.strip().splitlines()[-1].startswith("ok"), (r.stdout[-2000:], r.stderr[-3000:])
 
 
+def test_encode_batch_large_path_equals_dense_path(tok):
+    """Tokenize.encode_batch on 25 000 str (threaded packing -> CSR host path in a pinned arena -> dense arrays filled by host
+    threads) against encode_packed (dense device path) on the same documents, twice (the arena is reused), with and without
+    the whole-word tables."""
+    import corpus
+    text, offs, _ = corpus.config_corpus(3, n_docs=25000, seed=4)
+    raw = text.tobytes()
+    docs = [raw[offs[i]:offs[i + 1]].decode("utf-8") for i in range(len(offs) - 1)]
+    want = tok.encode_packed(text, offs, max_len=48)
+    for wt in (True, False, True):
+        got = tok.encode_batch(docs, max_len=48, word_table=wt)
+        assert got["input_ids"].shape == (25000, 48) and got["input_ids"].dtype == np.int32
+        assert np.array_equal(got["input_ids"], want["input_ids"]) and np.array_equal(got["attention_mask"], want["attention_mask"])
+        assert np.array_equal(got["n_real"], want["n_real"])
+    docs[17] = 3
+    with pytest.raises(TypeError, match="expected string or bytes-like object"):
+        tok.encode_batch(docs, max_len=48)
+
+
 def test_pinned_array_outlives_its_context():
     """A pinned array (gz_host_alloc) dropped AFTER its context was closed: gz_host_free must not touch the freed context."""
     import gc
