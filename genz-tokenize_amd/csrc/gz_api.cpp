@@ -317,7 +317,8 @@ int setup_text(gz_ctx* c, gz_ctx::TextWs& W, DBuf& tiny, const uint8_t* tb, cons
     if ((rc2 = ensure(c, W.brk, bm)) || (rc2 = ensure(c, W.st, bm)) || (rc2 = ensure(c, W.en, bm)) ||
         (rc2 = ensure(c, W.blkcnt, (size_t)(X.nblk + 2) * 4)) || (rc2 = ensure(c, W.docw0, (size_t)(n_docs + 2) * 4)) ||
         (rc2 = ensure(c, W.wtok, (size_t)wmax * 4)) || (rc2 = ensure(c, W.waux, (size_t)wmax * 4)) ||
-        (rc2 = ensure(c, W.mtok, (size_t)(Bt + 32) * 4)) || (rc2 = ensure(c, W.mlist, (size_t)wmax * 16)) ||
+        (rc2 = ensure(c, W.mtok, (size_t)(Bt + 32) * 8 + 64)) /* [0, B + 32): wide words, by byte offset; behind it: the compact token area */ ||
+        (rc2 = ensure(c, W.mlist, (size_t)wmax * 16)) ||
         (rc2 = ensure(c, W.grpblk, (size_t)(wmax / 64 + 4 + wmax / 1024 + 8) * 4)) ||
         (rc2 = ensure(c, W.blkmiss, (size_t)(X.nblk + 2) * 4)) ||
         (rc2 = ensure(c, W.tilecnt, (size_t)(X.nblk + 2) * 8)) || (rc2 = ensure(c, W.wlist, (size_t)(nbr + 64 + wmax + 8) * 4)) ||

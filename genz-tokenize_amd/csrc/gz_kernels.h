@@ -52,7 +52,7 @@ struct GzTextBufs {              // one text (A or B) of a batch and its per-cal
     uint32_t* tcnt;              // [words/1024 + 2] records of every 1 024-miss tile of mq that the merge kernel takes (gz_mpre_kernel)
     int64_t wmax;                // upper bound of the number of words (sizes of the per-word arrays)
     uint32_t* ctl;               // [64] zeroed per call: [0] words for gz_long_kernel, [1] ticket counter of gz_split_kernel, [2] [3] of the
-                                 // chained scans, [8 + c] misses of class c, [32 + c] sort cursor of class c; wlist == ctl + 64
+                                 // chained scans, [4] cursor of the compact token area; wlist == ctl + 64
     uint4* mq;                   // [words] the misses, tile by tile (1 024) sorted by symbol count: {word index, byte offset, record, 0}
     uint64_t* lookback;          // [nblk / 4 + 2] chained-scan words of gz_split_kernel {status:2, call:30, value:32}; never cleared
     uint32_t epoch;              // call number written into / expected in the chained-scan words
@@ -60,7 +60,8 @@ struct GzTextBufs {              // one text (A or B) of a batch and its per-cal
     uint32_t* wlist;             // [0] count, then the words (indices) that need 32 or 64 lanes (zeroed count per call); from the END of the
                                  // array down (wlist[wmax + 6 - k]): the words gz_long_kernel takes
     uint16_t* tilecnt;           // [4 * nblk] word starts of the block that lie before each of its four 1-KiB tiles
-    int32_t* mtok;               // [B+16]
+    int32_t* mtok;               // [2 (B + 32)]: [0, B + 32) tokens of wide / long words, at the word's byte offset; from B + 32 on the
+                                 // compact token area of gz_miss2_kernel (places handed out by gz_mpre_kernel, cursor: ctl[4])
 };
 
 struct GzAsmArgs {
