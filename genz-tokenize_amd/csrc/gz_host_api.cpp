@@ -59,6 +59,18 @@ int gz_host_tables_array(gz_host_tables* t, int which, const void** data, int64_
         case 3: *data = H.bmp.data();      *count = (int64_t)H.bmp.size(); break;
         case 4: *data = H.astral.data();   *count = (int64_t)H.astral.size(); break;
         case 5: *data = H.special_ids;     *count = 5; break;
+        // the perfect-hash form of the pair table: entries, displacement array, {nbuckets, bshift, sshift, slots, k1, k2, keys in
+        // overflow buckets}, hot set
+        case 6: *data = H.pair8.data();    *count = (int64_t)H.pair8.size(); break;
+        case 7: *data = H.pair_ph.disp.data(); *count = (int64_t)H.pair_ph.disp.size(); break;
+        case 8: {
+            static thread_local uint32_t ph[7];
+            const GzPhHost& P = H.pair_ph;
+            const uint32_t v[7] = {P.nbuckets, P.bshift, P.sshift, P.slots, P.k1, P.k2, P.n_overflow};
+            for (int i = 0; i < 7; ++i) ph[i] = v[i];
+            *data = ph; *count = 7; break;
+        }
+        case 9: *data = H.pair_hot.data(); *count = (int64_t)H.pair_hot.size(); break;
         default: return GZ_E_INVALID;
     }
     return GZ_OK;

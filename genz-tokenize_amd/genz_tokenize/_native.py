@@ -438,7 +438,8 @@ class HostTables:
     """gz_host_tables: the loader + table builder run on the host only (no GPU).  Used by the CPU test-suite to
     check the integer tables the kernels consume, and by tools that want to inspect them."""
 
-    _DT = {0: (np.uint32, 4), 1: (np.uint32, 4), 2: (np.int32, 2), 3: (np.uint32, 2), 4: (np.uint32, 4), 5: (np.int32, 1)}
+    _DT = {0: (np.uint32, 4), 1: (np.uint32, 4), 2: (np.int32, 2), 3: (np.uint32, 2), 4: (np.uint32, 4), 5: (np.int32, 1),
+           6: (np.uint32, 2), 7: (np.uint16, 1), 8: (np.uint32, 1), 9: (np.uint32, 2)}
 
     def __init__(self, vocab: bytes, bpe: bytes, specials=("<pad>", "<s>", "</s>", "<mask>", "<unk>")):
         self.lib = load_library()

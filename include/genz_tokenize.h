@@ -189,7 +189,11 @@ int  gz_timing_history(gz_ctx *ctx, double *out_ms, int32_t max, int32_t *n_out)
  * the integer tables it would upload exposed read-only.  `which`: 0 pair hash (uint32 x4 [slots]: left, right, merged symbol, rank; left = 0xFFFFFFFF: empty slot), 1 merges
  * (uint32 x4 [n_lines]: left,right,merged,0), 2 symbol ids (int32 x2 [n_symbols]: non-final, final), 3 BMP code
  * point table (uint32 x2 [65536]: plain, final), 4 astral table (uint32 x4 [slots]: cp,plain,final,0; may be
- * empty), 5 special ids (int32 [5]).  Pointers stay valid until gz_host_tables_destroy. */
+ * empty), 5 special ids (int32 [5]); the perfectly hashed pair table of the big pipeline's merge kernel: 6 entries (uint32 x2
+ * [slots]: left | right << 20, right >> 12 | alias flag << 8 | rank << 9; 0xFFFFFFFF x2: empty), 7 displacement array (uint16
+ * [buckets]), 8 its description (uint32 [7]: buckets, bucket shift, slot shift, slots, the two seeded multipliers, keys in
+ * overflow buckets), 9 the hot set staged in LDS (uint32 x2 [4096], same entry form).  Pointers stay valid until
+ * gz_host_tables_destroy (8: until the next call of this function on this thread). */
 typedef struct gz_host_tables gz_host_tables;
 int  gz_host_tables_create(const uint8_t *vocab, size_t vocab_len, const uint8_t *bpe, size_t bpe_len,
                            const char *const specials_utf8[5], gz_host_tables **out);

@@ -27,7 +27,7 @@ L.gz_host_tables_merge_entry.argtypes = [vp, i64, C.POINTER(vp), C.POINTER(i32),
 L.gz_host_tables_symbol.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(i32)]
 L.gz_last_error.argtypes = [vp]; L.gz_last_error.restype = C.c_char_p
 SPECIALS = ("<pad>", "<s>", "</s>", "<mask>", "<unk>")
-WIDTH = {0: 16, 1: 16, 2: 8, 3: 8, 4: 16, 5: 4}
+WIDTH = {0: 16, 1: 16, 2: 8, 3: 8, 4: 16, 5: 4, 6: 8, 7: 2, 8: 4, 9: 8}
 
 
 def build(vocab: bytes, bpe: bytes, specials=SPECIALS, read_all=True):
@@ -52,7 +52,7 @@ def build(vocab: bytes, bpe: bytes, specials=SPECIALS, read_all=True):
         i = 0
         while L.gz_host_tables_symbol(h, i, C.byref(p), C.byref(ln)) == 0:
             C.string_at(p, ln.value); i += 1
-        for which in range(6):
+        for which in range(10):
             assert L.gz_host_tables_array(h, which, C.byref(p), C.byref(n)) == 0
             if n.value:
                 C.string_at(p, n.value * WIDTH[which])               # touch every byte of the table

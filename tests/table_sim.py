@@ -31,6 +31,42 @@ class TableSim:
         self.bmp = H.array(3)
         self.astral = H.array(4)
         self.pad, self.bos, self.eos, _, self.unk = [int(x) for x in H.array(5)]
+        # the perfectly hashed form (gz_common.h): entries, displacement array, description, hot set
+        self.pair8 = H.array(6)
+        self.disp = H.array(7)
+        self.nbuckets, self.bshift, self.sshift, self.slots, self.k1, self.k2, self.n_overflow = [int(x) for x in H.array(8)]
+        self.hot = H.array(9)
+
+    PH_MUL, PH_OVERFLOW, HOT_SHIFT = 0x2C1B3C6D, 0xFFFF, 20
+
+    def probe8(self, a, b, use_hot=True):
+        """gz_miss2_kernel's lookup: hot set (LDS), else displacement -> ONE slot; overflow buckets probe on.  Returns
+        (rank, alias flag) or None."""
+        if (a | b) & 0xFFF00000:
+            return None
+        klo, khi = (a | (b << 20)) & M32, b >> 12
+        ha = (a * self.k1 + b * self.k2) & M32
+        hb = (a * 0xC2B2AE36 + b * 0x27D4EB2F) & M32
+
+        def match(e):
+            return int(e[0]) == klo and (int(e[1]) & 0xFF) == khi
+        if use_hot:
+            e = self.hot[ha >> self.HOT_SHIFT]
+            if match(e):
+                return int(e[1]) >> 9, (int(e[1]) >> 8) & 1
+        d = int(self.disp[ha >> self.bshift])
+        slot = (((hb ^ d) * self.PH_MUL) & M32) >> self.sshift
+        e = self.pair8[slot]
+        if match(e):
+            return int(e[1]) >> 9, (int(e[1]) >> 8) & 1
+        if d != self.PH_OVERFLOW:
+            return None
+        while int(e[0]) != M32 or int(e[1]) != M32:
+            slot = (slot + 1) & (self.slots - 1)
+            e = self.pair8[slot]
+            if match(e):
+                return int(e[1]) >> 9, (int(e[1]) >> 8) & 1
+        return None
 
     def probe(self, a, b):
         if (a | b) & 0xFFF00000:

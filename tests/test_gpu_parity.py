@@ -303,6 +303,23 @@ def test_dense_hash_tables():
     assert " passed" in r.stdout and "failed" not in r.stdout
 
 
+def test_perfect_hash_overflow_buckets_on_the_gpu():
+    """The perfectly hashed tables never need an overflow bucket on real files, so the kernels' "this bucket could not be
+    placed: probe on" branches (and the merge kernel's OVF instantiation) never run on the default build.
+    GZ_PH_FORCE_OVERFLOW=3 makes the builder refuse every third bucket -- several thousand keys of both tables then sit in
+    overflow buckets: the golden batches, the 20 k-document digests, the noisy corpora, long words and random tables run
+    again that way in a child process (table cache off, so that the tables are really rebuilt)."""
+    import subprocess
+    import sys
+    env = dict(os.environ, GZ_PH_FORCE_OVERFLOW="3", GZ_TABLE_CACHE="off")
+    here = os.path.abspath(__file__)
+    r = subprocess.run([sys.executable, "-m", "pytest", here, "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider", "-k",
+                        "g1_cases or g3_random or cfg3_20k or noisy_corpus or noisy_pairs or long_and_huge or random_tables_fuzz"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
+
+
 def test_small_kernel_shapes(tok, oracle_tables, sampler):
     """The one-launch path on its edge shapes, against the C oracle: documents of exactly 4 096 bytes (one per workgroup),
     64 tiny documents per workgroup, empty documents, every max_len class (1, 2, 3, odd, 1 024), a long word, a word of

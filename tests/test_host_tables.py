@@ -66,6 +66,76 @@ def test_pair_hash_complete(bundled):
     assert sim.probe(syms["n"], syms["n"]) == t.ranks.get(("n", "n"))
 
 
+def test_perfect_hash_pair_table_agrees_with_the_probing_one(bundled):
+    """The merge kernel's table (8-byte entries, hash and displace, hot set) against the linear-probing one, which the
+    test above ties to the oracle's bpe_ranks: every merge is found -- through the hot set and without it -- with its rank,
+    and the merged symbol IS the rank (symbols are numbered by rank; the bundled file has no two lines that spell the same
+    string); pairs that are no merges are refused; the table is dense (load > 0.7) and needs no overflow bucket."""
+    import random
+    H, sim, t = bundled
+    syms = {s: i for i, s in enumerate(H.symbols())}
+    assert sim.n_overflow == 0 and sim.slots == len(sim.pair8) and sim.nbuckets == len(sim.disp) and sim.nbuckets <= 16384
+    n = 0
+    for key, r in t.ranks.items():
+        if len(key) != 2:
+            continue
+        a, b = syms[key[0]], syms[key[1]]
+        for hot in (True, False):
+            assert sim.probe8(a, b, hot) == (r, 0), key
+        assert syms[key[0] + key[1]] == r                      # merged symbol == rank
+        n += 1
+    assert n / sim.slots > 0.7
+    rng = random.Random(8)
+    ids = list(syms.values())
+    members = {(syms[k[0]], syms[k[1]]) for k in t.ranks if len(k) == 2}
+    for _ in range(20000):
+        a, b = rng.choice(ids), rng.choice(ids)
+        if (a, b) not in members:
+            assert sim.probe8(a, b) is None and sim.probe(a, b) is None
+    assert sim.probe8(0x80000041, 5) is None                    # a code point outside every table never merges
+
+
+def test_perfect_hash_overflow_buckets_and_alias_flag():
+    """Forced overflow buckets (GZ_PH_FORCE_OVERFLOW: every third bucket is refused by the builder, as a table it cannot
+    place would be) and two merge lines that spell the same string (alias flag: the merged symbol is the smaller rank's),
+    in a child process (the switch is read once)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = r"""
+import os, sys
+root = %r
+for p in (root, os.path.join(root, "tests"), os.path.join(root, "oracle"), os.path.join(root, "genz-tokenize_amd")):
+    sys.path.insert(0, p)
+from genz_tokenize import _native
+from table_sim import TableSim
+import gz_oracle as O
+data = os.path.join(root, "genz-tokenize_amd", "genz_tokenize", "data")
+v = open(data + "/vocab.txt", "rb").read()
+b = open(data + "/bpe.codes", "rb").read()
+H = _native.HostTables(v, b); sim = TableSim(H); t = O.Tables(v, b)
+assert sim.n_overflow > 1000, sim.n_overflow
+syms = {s: i for i, s in enumerate(H.symbols())}
+for key, r in t.ranks.items():
+    if len(key) == 2:
+        assert sim.probe8(syms[key[0]], syms[key[1]], False) == (r, 0), key
+for txt in ("sinh_viên công_nghệ zzzqqqxx", "Trường đại_học Công_nghiệp", "a b c"):
+    assert sim.call(txt, max_len=16) == O.call(t, txt, max_len=16)
+# two lines spell "abc": ("a", "bc") at rank 2 and ("ab", "c") at rank 3 -> one symbol, id 2; rank 3 carries the alias flag
+bpe2 = "b c\na b\na bc\nab c\nabc d</w>\n".encode()
+voc2 = "abcd 5\nab@@ 4\nabc@@ 3\nd 2\na@@ 1\nbc@@ 1\nc@@ 1\nb@@ 1\n".encode()
+H2 = _native.HostTables(voc2, bpe2); s2 = TableSim(H2); t2 = O.Tables(voc2, bpe2)
+y = {s: i for i, s in enumerate(H2.symbols())}
+assert y["abc"] == 2 and s2.probe8(y["a"], y["bc"], False) == (2, 0) and s2.probe8(y["ab"], y["c"], False) == (3, 1)
+assert int(s2.merges[3][2]) == 2
+print("ok")
+""" % root
+    env = dict(os.environ, GZ_PH_FORCE_OVERFLOW="3")
+    r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-1500:], r.stderr[-3000:])
+
+
 def test_g1_through_tables(bundled):
     _, sim, _ = bundled
     n = sum(_cmp_call(sim, r) for r in read_jsonl("g1_cases.jsonl") if r["kind"] == "call")
