@@ -155,7 +155,6 @@ int  gz_word_token_counts(gz_ctx *ctx, int which_text, int32_t *counts, int64_t 
 int64_t gz_bpe_word(gz_ctx *ctx, const uint8_t *word_utf8, int64_t len, int32_t *pieces, int64_t cap);
 int  gz_symbol_utf8(gz_ctx *ctx, int32_t symbol, const uint8_t **utf8, int32_t *len);
 
-/* Device memory helpers so that a Python host needs nothing but ctypes (no torch in the product path). */
 /* Host path with the copies overlapped (SURVEY.md 8(d) timing (ii); replaces a loop of Tokenize.__call__ with
  * max_len, padding=True, truncation=True over host strings, tokenize.py:184-259): the result comes back in CSR form --
  * n_real[d] = entries of row d after truncation (tokenize.py:141-146), and the rows' real entries back to back in
@@ -164,12 +163,14 @@ int  gz_symbol_utf8(gz_ctx *ctx, int32_t symbol, const uint8_t **utf8, int32_t *
  * unless a real token equals the pad id (then mask = ids != pad, :148-152): a caller rebuilds them only where needed.
  * The batch is cut into sub-batches: text H2D, kernels and the D2H of the compact rows run on three streams.
  * `text` / `tokens` / `n_real` from gz_host_alloc (pinned) make both copies true DMA; pageable memory works, slower.
- * *total = entries written (or needed: GZ_E_CAPACITY).  Single texts only. */
+ * *total = entries written (or needed: GZ_E_CAPACITY).  Single texts only.
+ * gz_host_free does not use the context (a pinned block may outlive it): ctx may be NULL there. */
 int  gz_host_alloc(gz_ctx *ctx, size_t bytes, void **ptr);
 int  gz_host_free(gz_ctx *ctx, void *ptr);
 int  gz_encode_batch_csr(gz_ctx *ctx, const uint8_t *text, const int64_t *text_off, int64_t n_docs, int32_t max_len,
                          uint32_t flags, void *tokens, int64_t capacity, int32_t bits, int32_t *n_real, int64_t *total);
 
+/* Device memory helpers so that a Python host needs nothing but ctypes (no torch in the product path). */
 int  gz_device_alloc(gz_ctx *ctx, size_t bytes, void **dptr);
 int  gz_device_free(gz_ctx *ctx, void *dptr);
 int  gz_memcpy_h2d(gz_ctx *ctx, void *dst_device, const void *src_host, size_t bytes);
