@@ -115,7 +115,7 @@ struct gz_ctx {
     uint32_t lb_epoch = 0;               // call number of the chained scan (gz_split_kernel)   // [slot][text]
     hipStream_t stream2 = nullptr;       // sub-batches alternate between the two streams
     hipStream_t side = nullptr;          // the wide-word kernels of a text run here, beside the merge kernel
-    hipEvent_t ev_sf[2][2] = {}, ev_sj[2][2] = {};    // [slot][text]: fork / join of the side stream
+    hipEvent_t ev_sf0[2][2] = {}, ev_sf[2][2] = {}, ev_sj[2][2] = {};    // [slot][text]: forks / join of the side stream
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // exchange step (compact / gather / expand) on its own stream, so that it overlaps the next call's kernels
     hipStream_t xstream = nullptr;
@@ -236,7 +236,7 @@ int enqueue(gz_ctx* c)
         hipStream_t sk = (k & 1) ? c->stream2 : s;
         const GzAsmArgs& S = p.subs[k];
         for (int tx = 0; tx < S.n_texts; ++tx)
-            gz_launch_pipeline_text(T, c->dev, S.X[tx], S.n_docs, p.use_words, (int32_t*)c->w_flags.p + 3, sk, c->side, c->ev_sf[k & 1][tx], c->ev_sj[k & 1][tx]);
+            gz_launch_pipeline_text(T, c->dev, S.X[tx], S.n_docs, p.use_words, (int32_t*)c->w_flags.p + 3, sk, c->side, c->ev_sf0[k & 1][tx], c->ev_sf[k & 1][tx], c->ev_sj[k & 1][tx]);
         gz_launch_assemble(T, S, sk);
     }
     if (two) { HIPCHK(c, hipEventRecord(c->ev_join, c->stream2)); HIPCHK(c, hipStreamWaitEvent(s, c->ev_join, 0)); }
@@ -693,6 +693,7 @@ int gz_create(int device_id, gz_ctx** out)
     hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
     hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking);
     hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+    for (auto& a : c->ev_sf0) for (auto& e : a) hipEventCreateWithFlags(&e, hipEventDisableTiming);
     for (auto& a : c->ev_sf) for (auto& e : a) hipEventCreateWithFlags(&e, hipEventDisableTiming);
     for (auto& a : c->ev_sj) for (auto& e : a) hipEventCreateWithFlags(&e, hipEventDisableTiming);
     for (auto& e : c->ev_tok) hipEventCreateWithFlags(&e, hipEventDisableTiming);
@@ -715,6 +716,7 @@ void gz_destroy(gz_ctx* c)
     if (c->ev_x) hipEventDestroy(c->ev_x);
     if (c->xstream) hipStreamDestroy(c->xstream);
     if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
+    for (auto& a : c->ev_sf0) for (auto& e : a) if (e) hipEventDestroy(e);
     for (auto& a : c->ev_sf) for (auto& e : a) if (e) hipEventDestroy(e);
     for (auto& a : c->ev_sj) for (auto& e : a) if (e) hipEventDestroy(e);
     if (c->s_in) hipStreamDestroy(c->s_in);
@@ -1228,7 +1230,7 @@ int gz_encode_batch_csr(gz_ctx* c, const uint8_t* text, const int64_t* text_off,
             hipStreamSynchronize(c->s_in); hipStreamSynchronize(s); hipStreamSynchronize(c->s_out);
             return rc;
         }
-        gz_launch_pipeline_text(T, c->dev, A.X[0], A.n_docs, use_words, (int32_t*)c->w_flags.p + 3, s, c->side, c->ev_sf[k & 1][0], c->ev_sj[k & 1][0]);
+        gz_launch_pipeline_text(T, c->dev, A.X[0], A.n_docs, use_words, (int32_t*)c->w_flags.p + 3, s, c->side, c->ev_sf0[k & 1][0], c->ev_sf[k & 1][0], c->ev_sj[k & 1][0]);
         gz_launch_assemble(T, A, s);
         uint32_t* off32 = (uint32_t*)c->w_csr_off32.p;
         gz_launch_row_offsets(A.n_real, A.n_docs, off32, s);

@@ -74,10 +74,11 @@ struct GzAsmArgs {
 };
 
 // T_host: the host copy of the table descriptor (table sizes decide launch shapes)
-// side / ev_fork / ev_join (may be null): a second stream on which the rare wide-word kernels run beside the merge kernel
+// side / ev_fork0 / ev_fork / ev_join (may be null): a second stream on which gz_docw0_kernel runs beside the word kernel and
+// the rare wide-word kernels beside the merge kernel
 void gz_launch_pipeline_text(const GzDeviceTables* T_dev, const GzDeviceTables& T_host, const GzTextBufs& X, int64_t n_docs, int use_words,
                              int32_t* long_flag /* device int, zeroed by the caller */, hipStream_t s,
-                             hipStream_t side = nullptr, hipEvent_t ev_fork = nullptr, hipEvent_t ev_join = nullptr);
+                             hipStream_t side = nullptr, hipEvent_t ev_fork0 = nullptr, hipEvent_t ev_fork = nullptr, hipEvent_t ev_join = nullptr);
 void gz_launch_pick(const int64_t* off, const int64_t* off2, int64_t n_docs, int nsub, int64_t* out /* 2*(nsub+1) */, hipStream_t s);
 void gz_launch_row_offsets(const int32_t* n_real, int64_t n_rows, uint32_t* off, hipStream_t s);
 void gz_launch_compact(const int32_t* rows, const uint32_t* off, int64_t n_rows, int32_t row_len, void* out, int bits /* 32 | 16 */, hipStream_t s);
