@@ -96,6 +96,7 @@ struct gz_ctx {
         int32_t s_max_len = 0; int32_t* s_ids = nullptr; int32_t* s_mask = nullptr; int32_t* s_nreal = nullptr; int32_t* s_arena = nullptr;
         bool keep_words = false;
         bool chained = false;          // enqueued behind a call that has not been synchronised (its scan flag is kept)
+        bool inputs_resident = false;  // the caller's device buffers are readable now (no copy of them is queued on the stream)
     } pend;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
     // timed calls that were chained without a host sync in between: start / end of the main kernels of the last RING
@@ -115,7 +116,9 @@ struct gz_ctx {
     uint32_t lb_epoch = 0;               // call number of the chained scan (gz_split_kernel)   // [slot][text]
     hipStream_t stream2 = nullptr;       // sub-batches alternate between the two streams
     hipStream_t side = nullptr;          // the wide-word kernels of a text run here, beside the merge kernel
-    hipEvent_t ev_sf0[2][2] = {}, ev_sf[2][2] = {}, ev_sj[2][2] = {};    // [slot][text]: forks / join of the side stream
+    bool caller_buffers = false;   // set by the device entry points around encode_device_locked: text / offsets are the caller's
+                                   // own device buffers (readable now), not staging copies queued on the stream
+    hipEvent_t ev_sf0[2][2] = {}, ev_sf[2][2] = {}, ev_sj[2][2] = {}, ev_sb[2][2] = {};    // [slot][text]: forks / joins of the side stream
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     // exchange step (compact / gather / expand) on its own stream, so that it overlaps the next call's kernels
     hipStream_t xstream = nullptr;
@@ -236,7 +239,8 @@ int enqueue(gz_ctx* c)
         hipStream_t sk = (k & 1) ? c->stream2 : s;
         const GzAsmArgs& S = p.subs[k];
         for (int tx = 0; tx < S.n_texts; ++tx)
-            gz_launch_pipeline_text(T, c->dev, S.X[tx], S.n_docs, p.use_words, (int32_t*)c->w_flags.p + 3, sk, c->side, c->ev_sf0[k & 1][tx], c->ev_sf[k & 1][tx], c->ev_sj[k & 1][tx]);
+            gz_launch_pipeline_text(T, c->dev, S.X[tx], S.n_docs, p.use_words, (int32_t*)c->w_flags.p + 3, sk, c->side, c->ev_sf0[k & 1][tx], c->ev_sf[k & 1][tx], c->ev_sj[k & 1][tx],
+                                    p.inputs_resident ? c->ev_sb[k & 1][tx] : nullptr);
         gz_launch_assemble(T, S, sk);
     }
     if (two) { HIPCHK(c, hipEventRecord(c->ev_join, c->stream2)); HIPCHK(c, hipStreamWaitEvent(s, c->ev_join, 0)); }
@@ -309,6 +313,12 @@ int setup_text(gz_ctx* c, gz_ctx::TextWs& W, DBuf& tiny, const uint8_t* tb, cons
     }
     X.off = off;
     X.B = Bt;
+    {
+        // near records (gz_pipeline.inc, W_NEAR): GZ_NEAR_LIMIT shrinks the range so that small test batches reach the far form
+        uint32_t lim = 1u << 25;
+        if (const char* e = getenv("GZ_NEAR_LIMIT")) { const long v = atol(e); if (v >= 0 && v < (long)lim) lim = (uint32_t)v; }
+        X.near_lim = lim;
+    }
     X.nblk = Bt / 4096 + 1;
     const size_t bm = (size_t)((Bt + 1024) / 1024) * 128 + 64 + 4096;
     int64_t wmax = Bt / 2 + n_docs + 2; if (wmax > Bt + 2) wmax = Bt + 2;
@@ -391,6 +401,7 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
     const bool chained = p.active;                             // (still pending: this call goes behind it on the stream)
     p = gz_ctx::Pending();
     p.chained = chained;
+    p.inputs_resident = c->caller_buffers;
     p.timing = (flags & GZ_TIMING) != 0;
 
     // Sub-batches: contiguous document ranges (dense layouts of large batches only).  Their byte positions are the
@@ -694,6 +705,7 @@ int gz_create(int device_id, gz_ctx** out)
     hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking);
     hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
     for (auto& a : c->ev_sf0) for (auto& e : a) hipEventCreateWithFlags(&e, hipEventDisableTiming);
+    for (auto& a : c->ev_sb) for (auto& e : a) hipEventCreateWithFlags(&e, hipEventDisableTiming);
     for (auto& a : c->ev_sf) for (auto& e : a) hipEventCreateWithFlags(&e, hipEventDisableTiming);
     for (auto& a : c->ev_sj) for (auto& e : a) hipEventCreateWithFlags(&e, hipEventDisableTiming);
     for (auto& e : c->ev_tok) hipEventCreateWithFlags(&e, hipEventDisableTiming);
@@ -717,6 +729,7 @@ void gz_destroy(gz_ctx* c)
     if (c->xstream) hipStreamDestroy(c->xstream);
     if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
     for (auto& a : c->ev_sf0) for (auto& e : a) if (e) hipEventDestroy(e);
+    for (auto& a : c->ev_sb) for (auto& e : a) if (e) hipEventDestroy(e);
     for (auto& a : c->ev_sf) for (auto& e : a) if (e) hipEventDestroy(e);
     for (auto& a : c->ev_sj) for (auto& e : a) if (e) hipEventDestroy(e);
     if (c->s_in) hipStreamDestroy(c->s_in);
@@ -928,8 +941,11 @@ int gz_encode_batch_device(gz_ctx* c, const uint8_t* text, const int64_t* text_o
     if (!c) return GZ_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
-    return encode_device_locked(c, text, text_off, pair, pair_off, n_docs, max_len, flags, capacity, input_ids,
+    c->caller_buffers = true;
+    const int rc = encode_device_locked(c, text, text_off, pair, pair_off, n_docs, max_len, flags, capacity, input_ids,
                                 attention_mask, token_type_ids, sequence_id, row_off, pair_len, n_real, status, nullptr, nullptr);
+    c->caller_buffers = false;
+    return rc;
 }
 
 int gz_encode_batch_device_h(gz_ctx* c, const uint8_t* text, const int64_t* text_off, const uint8_t* pair,
@@ -943,9 +959,12 @@ int gz_encode_batch_device_h(gz_ctx* c, const uint8_t* text, const int64_t* text
         return fail(c, GZ_E_INVALID, "host copies of the offsets are required for every text");
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
-    return encode_device_locked(c, text, text_off, pair, pair_off, n_docs, max_len, flags, capacity, input_ids,
+    c->caller_buffers = true;
+    const int rc = encode_device_locked(c, text, text_off, pair, pair_off, n_docs, max_len, flags, capacity, input_ids,
                                 attention_mask, token_type_ids, sequence_id, row_off, pair_len, n_real, status,
                                 text_off_host, pair_off_host);
+    c->caller_buffers = false;
+    return rc;
 }
 
 int gz_sync(gz_ctx* c)
@@ -1289,7 +1308,7 @@ int gz_word_token_counts(gz_ctx* c, int which_text, int32_t* counts, int64_t cap
         if (total) {
             std::vector<uint32_t> wt(total);
             HIPCHK(c, hipMemcpy(wt.data(), X.wtok, (size_t)total * 4, hipMemcpyDeviceToHost));
-            for (uint32_t w = 0; w < total; ++w) counts[wbase + w] = (wt[w] & 0x80000000u) ? (int32_t)(wt[w] & 0x0FFFFFFFu) : 1;
+            for (uint32_t w = 0; w < total; ++w) counts[wbase + w] = !(wt[w] & 0x80000000u) ? 1 : (wt[w] & 0x20000000u) ? (int32_t)((wt[w] >> 25) & 15u) + 1 : (int32_t)(wt[w] & 0x0FFFFFFFu);   // (record forms: gz_pipeline.inc, W_NEAR)
         }
         wbase += total; dbase += S.n_docs;
     }

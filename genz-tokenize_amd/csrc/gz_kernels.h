@@ -44,8 +44,8 @@ struct GzTextBufs {              // one text (A or B) of a batch and its per-cal
     uint16_t* en;
     uint32_t* blkcnt;            // [nblk+1] words per block, then (scanned in place) index of each block's first word
     uint32_t* docw0;             // [n_docs+1] index of each document's first word
-    uint32_t* wtok;              // [words] id, or MISS | token count
-    uint32_t* waux;              // [words] misses: byte offset of the word (its ids are at mtok[offset ...])
+    uint32_t* wtok;              // [words] id, or a merged word's record (far: MISS | token count; near: count and place in one word)
+    uint32_t* waux;              // [words] far records only: where the word's tokens are (mtok[waux ...]; wide / long words: their byte offset)
     uint4* mlist;                // [words] the misses of block b, compact, at mlist[blkcnt[b] ...]: {word index, byte offset, pending record, 0}
     uint32_t* blkmiss;           // [nblk+1] number of misses per block; scanned in place before gz_miss_kernel ([nblk] = total)
     uint32_t* grpblk;            // [words/64 + 2] block that holds miss number 64 g (written by the scan)
@@ -56,6 +56,7 @@ struct GzTextBufs {              // one text (A or B) of a batch and its per-cal
     uint4* mq;                   // [words] the misses, tile by tile (1 024) sorted by symbol count: {word index, byte offset, record, 0}
     uint64_t* lookback;          // [nblk / 4 + 2] chained-scan words of gz_split_kernel {status:2, call:30, value:32}; never cleared
     uint32_t epoch;              // call number written into / expected in the chained-scan words
+    uint32_t near_lim;           // places of the compact token area below this get near records (2^25; GZ_NEAR_LIMIT: smaller, for tests)
     uint32_t* blklong;           // [nblk] block holds a word for gz_long_kernel (zeroed per call)
     uint32_t* wlist;             // [0] count, then the words (indices) that need 32 or 64 lanes (zeroed count per call); from the END of the
                                  // array down (wlist[wmax + 6 - k]): the words gz_long_kernel takes
@@ -78,7 +79,9 @@ struct GzAsmArgs {
 // the rare wide-word kernels beside the merge kernel
 void gz_launch_pipeline_text(const GzDeviceTables* T_dev, const GzDeviceTables& T_host, const GzTextBufs& X, int64_t n_docs, int use_words,
                              int32_t* long_flag /* device int, zeroed by the caller */, hipStream_t s,
-                             hipStream_t side = nullptr, hipEvent_t ev_fork0 = nullptr, hipEvent_t ev_fork = nullptr, hipEvent_t ev_join = nullptr);
+                             hipStream_t side = nullptr, hipEvent_t ev_fork0 = nullptr, hipEvent_t ev_fork = nullptr, hipEvent_t ev_join = nullptr,
+                             hipEvent_t ev_brk = nullptr /* non-null: X.off is readable NOW (no copy of it is queued on s): the document-start
+                                                            bits are prepared on the side stream, under whatever s is still running */);
 void gz_launch_pick(const int64_t* off, const int64_t* off2, int64_t n_docs, int nsub, int64_t* out /* 2*(nsub+1) */, hipStream_t s);
 void gz_launch_row_offsets(const int32_t* n_real, int64_t n_rows, uint32_t* off, hipStream_t s);
 void gz_launch_compact(const int32_t* rows, const uint32_t* off, int64_t n_rows, int32_t row_len, void* out, int bits /* 32 | 16 */, hipStream_t s);

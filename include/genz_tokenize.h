@@ -122,7 +122,9 @@ int  gz_encode_batch(gz_ctx *ctx,
 /* The same call with every pointer a DEVICE pointer on the context's GPU (inputs already resident in HBM,
  * outputs left in HBM).  Work is enqueued on the context's stream; gz_sync waits for it and returns the
  * deferred error of the enqueued work, if any.  Only the dense layout and the ragged layout with a
- * sufficient capacity are available here (GZ_E_CAPACITY is reported by gz_sync). */
+ * sufficient capacity are available here (GZ_E_CAPACITY is reported by gz_sync).
+ * The input buffers must be COMPLETE when the call is made (whatever wrote them has been synchronised): the library reads
+ * them on its own streams, which know nothing of the caller's, and part of that reading starts at once. */
 int  gz_encode_batch_device(gz_ctx *ctx,
                             const uint8_t *text, const int64_t *text_off,
                             const uint8_t *pair, const int64_t *pair_off,

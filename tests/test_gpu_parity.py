@@ -320,6 +320,23 @@ def test_perfect_hash_overflow_buckets_on_the_gpu():
     assert " passed" in r.stdout and "failed" not in r.stdout
 
 
+def test_far_word_records_on_small_batches():
+    """A merged word's record has two forms (gz_pipeline.inc, W_NEAR): "near" -- count and place of its tokens in the record
+    itself, for the first 2^25 places of the compact token area -- and "far" (count in the record, place in waux).  Batches
+    below some 10 M merged words only ever produce near records: GZ_NEAR_LIMIT=300 gives the far form to every word placed
+    from 300 on, so that the golden batches, the 20 k-document digests, the noisy corpora, the word-count output and the long
+    words see BOTH forms side by side, in a child process with the small batches sent through the kernel pipeline."""
+    import subprocess
+    import sys
+    env = dict(os.environ, GZ_NEAR_LIMIT="300", GZ_SMALL="0")
+    here = os.path.abspath(__file__)
+    r = subprocess.run([sys.executable, "-m", "pytest", here, "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider", "-k",
+                        "g1_cases or g3_random or cfg3_20k or noisy_corpus or noisy_pairs or long_and_huge or csr_host_path or large_noisy or extreme_batch"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
+
+
 def test_small_kernel_shapes(tok, oracle_tables, sampler):
     """The one-launch path on its edge shapes, against the C oracle: documents of exactly 4 096 bytes (one per workgroup),
     64 tiny documents per workgroup, empty documents, every max_len class (1, 2, 3, odd, 1 024), a long word, a word of
