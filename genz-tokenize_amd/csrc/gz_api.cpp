@@ -1548,9 +1548,28 @@ int preprocess_device_locked(gz_ctx* c, const int32_t* ops, int32_t n_ops, const
     }
     const uint8_t* in = text_dev;
     const int64_t* in_len = nullptr;
-    for (int k = 0; k < n_ops; ++k) {
+    // documents of at most 4 KiB: the whole chain in one kernel, on chip (GZ_PP_FUSED=0: filter by filter like the long ones)
+    static const int fused = getenv("GZ_PP_FUSED") ? atoi(getenv("GZ_PP_FUSED")) : 1;
+    bool chain = true;
+    if (fused) {
+        GzPpFusedArgs F{};
+        F.in = text_dev; F.in_off = off_dev; F.n_docs = n_docs;
+        F.out = (uint8_t*)c->w_pp[(n_ops - 1) & 1].p; F.out_len = (int64_t*)c->w_ppoff[(n_ops - 1) & 1].p;
+        F.n_ops = n_ops;
+        for (int k = 0; k < n_ops; ++k) F.ops[k] = ops[k];
+        // (the kernel counts the documents it leaves to the chain below: none, as a rule -- then the chain is not launched)
+        F.n_long = (uint32_t*)c->w_ppaux.p + 2 * (n_docs + 1) - 2;           // the last 8 bytes of the aux array (entry n_docs: unused)
+        HIPCHK(c, hipMemsetAsync(F.n_long, 0, 4, c->stream));
+        gz_launch_preprocess_fused(F, c->stream);
+        uint32_t n_long = 0;
+        HIPCHK(c, hipMemcpyAsync(&n_long, F.n_long, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        if (n_long == 0) { chain = false; in = F.out; in_len = F.out_len; }
+    }
+    for (int k = 0; chain && k < n_ops; ++k) {
         GzPpArgs A{};
         A.in = in; A.in_off = off_dev; A.in_len = in_len; A.n_docs = n_docs; A.op = ops[k];
+        A.skip_upto = fused ? GZ_PP_FUSED_MAX_BYTES : -1;
         A.in_abs = k == 0 ? 1 : 0;                                                         // the caller's text; later filters read their own slot buffers
         A.out = (uint8_t*)c->w_pp[k & 1].p; A.out_len = (int64_t*)c->w_ppoff[k & 1].p; A.aux = (int64_t*)c->w_ppaux.p;
         if (ops[k] == GZ_PP_HTML) gz_launch_preprocess(A, 0, c->stream);                  // does the last '<' close?

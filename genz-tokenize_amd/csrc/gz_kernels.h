@@ -116,8 +116,21 @@ struct GzPpArgs {
     int64_t* out_len;                           // pass 1: the new lengths
     int64_t* aux;                               // [n_docs] html: position of the unclosed '<' (pass 0 -> pass 1)
     int32_t op;                                 // GZ_PP_*
+    int64_t skip_upto;                          // documents whose INPUT slot is at most this long are left alone (gz_pp_fused_kernel did them); -1: none
 };
+struct GzPpFusedArgs {                          // the whole chain for short documents, on chip (gz_pp_fused_kernel)
+    const uint8_t* in; const int64_t* in_off;   // the caller's text, absolute offsets
+    int64_t n_docs;
+    uint8_t* out; int64_t* out_len;             // the documents' slots of the chain's LAST buffer, their final lengths
+    int32_t n_ops; int32_t ops[16];
+    uint32_t* n_long;                           // += documents too long for this kernel (zeroed by the caller)
+};
+#ifndef GZ_PPF_CAP
+#define GZ_PPF_CAP 4096
+#endif
+constexpr int GZ_PP_FUSED_MAX_BYTES = GZ_PPF_CAP;     // == PPF_CAP (gz_preproc.inc)
 void gz_launch_preprocess(const GzPpArgs& A, int pass, hipStream_t s);
+void gz_launch_preprocess_fused(const GzPpFusedArgs& A, hipStream_t s);
 void gz_launch_scan64(const int64_t* len, int64_t n, int64_t* out_off /* n+1 */, hipStream_t s);
 void gz_launch_pp_pack(const uint8_t* in, const int64_t* in_off, const int64_t* len, int64_t n_docs, uint8_t* out, const int64_t* out_off,
                        hipStream_t s);

@@ -550,6 +550,13 @@ void gz_launch_scan64(const int64_t* len, int64_t n, int64_t* out_off /* n+1 */,
     hipLaunchKernelGGL(gz_scan_kernel, dim3(1), dim3(1024), 0, s, len, n, out_off);
 }
 
+void gz_launch_preprocess_fused(const GzPpFusedArgs& A, hipStream_t s)
+{
+    static_assert(PPF_CAP == GZ_PP_FUSED_MAX_BYTES, "gz_kernels.h and gz_preproc.inc disagree");
+    if (A.n_docs <= 0) return;
+    hipLaunchKernelGGL(gz_pp_fused_kernel, dim3((unsigned)((A.n_docs + PPF_WPB - 1) / PPF_WPB)), dim3(WAVE * PPF_WPB), 0, s, A);
+}
+
 void gz_launch_pp_pack(const uint8_t* in, const int64_t* in_off, const int64_t* len, int64_t n_docs, uint8_t* out, const int64_t* out_off, hipStream_t s)
 {
     if (n_docs > 0)

@@ -292,7 +292,12 @@ class Context:
         counts = np.empty(max(capacity, 1), dtype=np.int32)
         first = np.zeros(n_docs + 1, dtype=np.int64)
         nw = C.c_int64()
-        self._check(self.lib.gz_word_token_counts(self.handle, which_text, _ptr(counts), capacity, _ptr(first), C.byref(nw)))
+        rc = self.lib.gz_word_token_counts(self.handle, which_text, _ptr(counts), capacity, _ptr(first), C.byref(nw))
+        if rc == GZ_E_CAPACITY and nw.value > capacity:         # the call says how many words there are: once more, exactly
+            capacity = int(nw.value)
+            counts = np.empty(capacity, dtype=np.int32)
+            rc = self.lib.gz_word_token_counts(self.handle, which_text, _ptr(counts), capacity, _ptr(first), C.byref(nw))
+        self._check(rc)
         return counts[:nw.value], first
 
     def bpe_word(self, word: bytes):

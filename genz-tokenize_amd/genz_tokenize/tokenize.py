@@ -272,18 +272,66 @@ class Tokenize(object):
     # ---- batch API (new) -----------------------------------------------------------------------------------------
     def encode_batch(self, texts: Sequence[str], pair_texts: Optional[Sequence[str]] = None,
                      max_len: Optional[int] = None, padding: bool = True, truncation: bool = True,
-                     word_table: bool = True):
+                     word_table: bool = True, return_offset: bool = False):
         """`__call__` over many documents in one launch.  With max_len >= 1, padding and truncation the result
         arrays are [N, max_len] int32; otherwise they are flat with `row_off` [N+1].  `status[i] == 1` marks a
-        document for which the single-call API raises ValueError."""
+        document for which the single-call API raises ValueError.
+        `return_offset=True` adds `__call__`'s 'offset' lists for every document (tokenize.py:105, :111-117, :225-234) as two
+        arrays: `offset` int32 [E, 2] -- the (first, last) spans of all documents one after the other -- and `offset_off`
+        int64 [N+1]: document i's list is offset[offset_off[i]:offset_off[i+1]] (`offsets_of(result, i)` gives it in the
+        reference's list-of-tuples form)."""
         if pair_texts is not None and len(pair_texts) != len(texts):
             raise ValueError("texts and pair_texts differ in length")
         if (pair_texts is None and padding and truncation and max_len is not None and int(max_len) >= 1 and len(texts) >= 20000
-                and _packing._gz_pack is not None):
+                and _packing._gz_pack is not None and not return_offset):
             return self._encode_batch_large(texts, int(max_len), word_table)
         r = self._run(list(texts), None if pair_texts is None else list(pair_texts), max_len, padding, truncation,
-                      word_table)
-        return self._shape(r, len(texts))
+                      word_table, keep_words=bool(return_offset))
+        out = self._shape(r, len(texts))
+        if return_offset:
+            out["offset"], out["offset_off"] = self._batch_offsets(len(texts), pair_texts is not None)
+        return out
+
+    def _batch_offsets(self, n, is_pair):
+        """The 'offset' lists of the last batch call, from the per-word piece counts the device kept (GZ_KEEP_WORDS): per text
+        [(0, 0)] + one 1-based (first, last) token span per word + (T+1, T+1) (tokenize.py:105, :111-117); in pair mode B's
+        entries follow A's, each shifted by the NUMBER OF ENTRIES of A (tokenize.py:231-234: `len(offset)`, not tokens)."""
+        def spans(which):
+            counts, first = self._ctx.word_token_counts(which, n, 1 << 16)
+            first = first.astype(np.int64)
+            nw = np.diff(first)
+            eoff = first + 2 * np.arange(n + 1, dtype=np.int64)          # entries before document d: its words + 2 per document
+            cs = np.zeros(len(counts) + 1, dtype=np.int64)
+            np.cumsum(counts, out=cs[1:])
+            base = cs[first[:-1]]
+            out = np.zeros((int(eoff[-1]), 2), dtype=np.int64)
+            doc = np.repeat(np.arange(n, dtype=np.int64), nw)
+            w = np.arange(len(counts), dtype=np.int64)
+            pos = w + 2 * doc + 1
+            out[pos, 0] = cs[:-1] - base[doc] + 1
+            out[pos, 1] = cs[1:] - base[doc]
+            T = cs[first[1:]] - base
+            out[eoff[1:] - 1] = (T + 1)[:, None]
+            return out, eoff
+        a, ea = spans(0)
+        if not is_pair:
+            return a.astype(np.int32), ea
+        b, eb = spans(1)
+        na, nb = np.diff(ea), np.diff(eb)
+        b += np.repeat(na, nb)[:, None]                              # rule O2: shifted by A's entry count
+        eoff = ea + eb
+        out = np.empty((int(eoff[-1]), 2), dtype=np.int64)
+        ia = np.arange(len(a), dtype=np.int64) + np.repeat(eb[:-1], na)          # A's entries of document d move up by B's earlier ones
+        ib = np.arange(len(b), dtype=np.int64) + np.repeat(ea[1:], nb)           # B's follow A's of the same document
+        out[ia] = a
+        out[ib] = b
+        return out.astype(np.int32), eoff
+
+    @staticmethod
+    def offsets_of(result, i):
+        """Document i's 'offset' list of an `encode_batch(..., return_offset=True)` result, as `__call__` returns it."""
+        lo, hi = int(result["offset_off"][i]), int(result["offset_off"][i + 1])
+        return [(int(a), int(b)) for a, b in result["offset"][lo:hi]]
 
     def _encode_batch_large(self, texts, max_len, word_table):
         """Large dense single-text batches: the strings are packed on threads (csrc/gz_pack.c), the packed text goes through

@@ -101,3 +101,44 @@ def test_host_expand_of_csr_rows_matches_numpy():
     with pytest.raises(ValueError):
         _packing._gz_pack.expand(np.zeros(3, np.uint16), 16, np.array([2, 2], np.int32), np.array([0, 2, 4], np.int64), 4, 0,
                                  np.empty((2, 4), np.int32), np.empty((2, 4), np.int32))       # fewer entries than the rows announce
+
+
+def test_batch_offset_spans_from_word_counts():
+    """Host logic of `encode_batch(..., return_offset=True)`: the numpy span arithmetic over per-word piece counts against the
+    list form of tokenize.py:105, :111-117 (and :231-234 for pairs: B's entries shifted by A's entry count), with a fake
+    context that serves random counts -- documents without words included."""
+    import numpy as np
+    from genz_tokenize.tokenize import Tokenize
+
+    class Ctx:
+        def __init__(self, per_text):
+            self.t = per_text
+
+        def word_token_counts(self, which, n, cap):
+            docs = self.t[which]
+            counts = np.array([c for d in docs for c in d], dtype=np.int32)
+            first = np.zeros(n + 1, np.int64)
+            np.cumsum([len(d) for d in docs], out=first[1:])
+            return counts, first
+
+    def ref(doc):
+        off, seen = [(0, 0)], 0
+        for c in doc:
+            off.append((seen + 1, seen + c)); seen += c
+        off.append((seen + 1, seen + 1))
+        return off
+
+    rng = np.random.default_rng(1)
+    n = 64
+    A = [list(map(int, rng.integers(1, 5, size=rng.integers(0, 6)))) for _ in range(n)]
+    B = [list(map(int, rng.integers(1, 5, size=rng.integers(0, 6)))) for _ in range(n)]
+    t = Tokenize.__new__(Tokenize)
+    t._ctx = Ctx([A, B])
+    o, e = t._batch_offsets(n, False)
+    r = dict(offset=o, offset_off=e)
+    assert o.dtype == np.int32 and all(Tokenize.offsets_of(r, i) == ref(A[i]) for i in range(n))
+    o, e = t._batch_offsets(n, True)
+    r = dict(offset=o, offset_off=e)
+    for i in range(n):
+        ra = ref(A[i])
+        assert Tokenize.offsets_of(r, i) == ra + [(a + len(ra), b + len(ra)) for a, b in ref(B[i])], i

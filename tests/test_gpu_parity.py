@@ -733,6 +733,29 @@ def test_encode_batch_large_path_equals_dense_path(tok):
         tok.encode_batch(docs, max_len=48)
 
 
+def test_batch_return_offset_equals_single_calls(tok, sampler):
+    """`encode_batch(..., return_offset=True)`: every document's 'offset' list (one span per word from the device's per-word
+    piece counts; pair mode: B's entries shifted by A's ENTRY count, tokenize.py:231-234) equals the list `__call__` returns for
+    that document alone -- the form the reference-generated G1 / G3 rows pin.  Noisy documents, empty and whitespace-only
+    ones, glued line feeds, long words; single texts and pairs; dense and ragged layouts."""
+    text, offs, _ = corpus.config_corpus(3, n_docs=160, seed=77, sampler=sampler)
+    text, offs = corpus.add_noise(text, offs, seed=5, rate=0.05)
+    raw = text.tobytes()
+    docs = [raw[offs[i]:offs[i + 1]].decode("utf-8", "ignore") for i in range(len(offs) - 1)]
+    docs += ["", " ", "\n", "a", "ab\ncd\n\nef", "x" * 70 + " y", "\u1ea5" * 40, "kh\u00f4ng \u0111\u01b0\u1ee3c", "a\u2003b\u00a0c"]
+    pairs = docs[7:] + docs[:7]
+    for ml, pad, trunc in ((32, True, True), (None, True, True), (16, False, True)):
+        r = tok.encode_batch(docs, max_len=ml, padding=pad, truncation=trunc, return_offset=True)
+        assert len(r["offset_off"]) == len(docs) + 1 and r["offset"].shape == (int(r["offset_off"][-1]), 2)
+        for i, d in enumerate(docs):
+            assert tok.offsets_of(r, i) == tok(d, max_len=ml, padding=pad, truncation=trunc, return_offset=True)["offset"], (ml, i, d[:40])
+    r = tok.encode_batch(docs, pairs, max_len=None, return_offset=True)
+    for i, (a, b) in enumerate(zip(docs, pairs)):
+        assert tok.offsets_of(r, i) == tok(a, b, return_offset=True)["offset"], (i, a[:30], b[:30])
+    # without the switch the result has no such keys, and the large-batch path is not taken with it
+    assert "offset" not in tok.encode_batch(docs[:4], max_len=8)
+
+
 def test_pinned_array_outlives_its_context():
     """A pinned array (gz_host_alloc) dropped AFTER its context was closed: gz_host_free must not touch the freed context."""
     import gc
@@ -991,6 +1014,42 @@ def test_preprocess_long_documents_vs_oracle():
         got = P.preprocess_batch(docs, ops)
         for d, g in zip(docs, got):
             assert g == O.preprocess(d, ops), (ops, d[:80])
+
+
+def test_preprocess_fused_and_filter_by_filter_paths():
+    """Documents of at most 4 096 bytes run their whole filter chain in one kernel, on chip (gz_pp_fused_kernel, with filters
+    skipped when a look at the bytes shows they cannot apply); longer ones go filter by filter through HBM.  Both against the
+    oracle around the size limit -- 4 094 ... 4 098 bytes with tags, URLs, combining marks, emoji and whitespace runs at the
+    very end -- mixed in one batch; and the reference-generated G7 rows + the long-document comparison once more with
+    GZ_PP_FUSED=0 (everything filter by filter) in a child process."""
+    import random
+    import subprocess
+    import sys
+    from genz_tokenize import preprocess as P
+    r = random.Random(5)
+    tails = ["<b>x</b>", "http://a.vn/b c", "a\u0300", "\u00e2\u0301", "\U0001F600 ", "  \u3000 ", "<unclosed", "x!?", "https", "\u0300"]
+    fill = ["vi\u1ec7t ", "nam ", "a", " ", "<i>", "</i>", "!", "http://x ", "e\u0301", "\u2764"]
+    docs = []
+    for size in (2048, 4094, 4095, 4096, 4097, 4098, 9000):
+        for t in tails:
+            body = ""
+            while len((body + t).encode("utf-8")) < size - 8:
+                body += r.choice(fill)
+            d = body + t
+            pad = size - len(d.encode("utf-8"))
+            docs.append("x" * max(pad, 0) + d)
+            assert abs(len(docs[-1].encode("utf-8")) - size) <= 8
+    docs += ["", "a", "<", "http", "a" * 4096, "<" * 4096, " " * 4095 + "a", " " * 4096 + "a"]
+    for ops in (["html", "unicode", "punct", "emoji", "url"], ["url", "emoji"], ["emoji"], ["html"], ["unicode", "html"]):
+        got = P.preprocess_batch(docs, ops)
+        for d, g in zip(docs, got):
+            assert g == O.preprocess(d, ops), (ops, len(d.encode("utf-8")), d[-40:])
+    env = dict(os.environ, GZ_PP_FUSED="0")
+    here = os.path.abspath(__file__)
+    c = subprocess.run([sys.executable, "-m", "pytest", here, "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider", "-k",
+                        "g7_preprocess or preprocess_long_documents"], env=env, capture_output=True, text=True, timeout=600)
+    assert c.returncode == 0, c.stdout[-3000:] + c.stderr[-2000:]
+    assert " passed" in c.stdout and "failed" not in c.stdout
 
 
 def test_device_handoff_dlpack():
