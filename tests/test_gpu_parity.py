@@ -320,6 +320,24 @@ def test_perfect_hash_overflow_buckets_on_the_gpu():
     assert " passed" in r.stdout and "failed" not in r.stdout
 
 
+@pytest.mark.parametrize("switches", [{"GZ_HOT": "0", "GZ_SIDE": "0", "GZ_BRK_SIDE": "0"}, {"GZ_ASSEMBLE": "2"}, {"GZ_ASSEMBLE": "1"}],
+                         ids=["linear_probing_kernels_one_stream", "lds_row_kernel", "scatter_row_kernel"])
+def test_alternative_kernels_stay_exact(switches):
+    """Kernels the library keeps beside the default ones: the linear-probing word / merge kernels of rounds 1-2 (GZ_HOT=0; also
+    everything on one stream, GZ_SIDE=0 / GZ_BRK_SIDE=0), and the two older row writers for dense single texts (GZ_ASSEMBLE=2:
+    whole rows through LDS, the pair-mode kernel; 1: the scatter kernel of the ragged layouts).  Each runs the golden batches,
+    the 20 k-document digests, the noisy corpora and the long words in a child process, small batches through the pipeline."""
+    import subprocess
+    import sys
+    env = dict(os.environ, GZ_SMALL="0", **switches)
+    here = os.path.abspath(__file__)
+    r = subprocess.run([sys.executable, "-m", "pytest", here, "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider", "-k",
+                        "g1_cases or g3_random_batched or cfg3_20k or noisy_corpus or long_and_huge or extreme_batch"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
+
+
 def test_far_word_records_on_small_batches():
     """A merged word's record has two forms (gz_pipeline.inc, W_NEAR): "near" -- count and place of its tokens in the record
     itself, for the first 2^25 places of the compact token area -- and "far" (count in the record, place in waux).  Batches
