@@ -570,8 +570,9 @@ static int build_word_table(gz_ctx* c, WordImages& W)
         uint8_t key[32] = {0};
         std::memcpy(key, text.data() + off[i], len);
         if (len <= 16) {
-            GzWordSlot1 e1{0, 0, len | ((uint32_t)id << 5), {0, 0, 0}};
-            std::memcpy(&e1.lo, key, 8); std::memcpy(&e1.hi, key + 8, 8);
+            GzWordSlot1 e1{};
+            e1.meta = len | ((uint32_t)id << 5);
+            std::memcpy(e1.k, key, 12); std::memcpy(&e1.k3, key + 12, 4);
             found1.push_back(e1);
         }
         if (len <= 12) {
@@ -599,14 +600,14 @@ static int build_word_table(gz_ctx* c, WordImages& W)
     {
         // the words of <= 16 bytes, perfectly hashed (the big pipeline's word kernel: one line per probe, gz_common.h)
         std::vector<uint32_t> hb(found1.size()), slot_of;
-        for (size_t i = 0; i < found1.size(); ++i) hb[i] = gz_word1_hb(found1[i].lo, found1[i].hi, found1[i].meta & 31u);
+        for (size_t i = 0; i < found1.size(); ++i) hb[i] = gz_word1_hb(gz_slot1_lo(found1[i]), gz_slot1_hi(found1[i]), found1[i].meta & 31u);
         auto ha = [](const void* ctx, size_t i, uint32_t k1, uint32_t k2) -> uint32_t {
             const GzWordSlot1& e = (*static_cast<const std::vector<GzWordSlot1>*>(ctx))[i];
-            return gz_word1_ha(e.lo, e.hi, e.meta & 31u, k1, k2);
+            return gz_word1_ha(gz_slot1_lo(e), gz_slot1_hi(e), e.meta & 31u, k1, k2);
         };
         GzPhHost& ph = W.ph;
         gz_ph_build(found1.size(), ha, &found1, hb.data(), ph, slot_of);
-        W.tabp.assign(ph.slots, GzWordSlot1{0, 0, 0, {0, 0, 0}});
+        W.tabp.assign(ph.slots, GzWordSlot1{});
         for (size_t i = 0; i < found1.size(); ++i) W.tabp[slot_of[i]] = found1[i];
         // hot set: the words the vocab file counts most often (no counts: the file's order), direct-mapped by the top bits of ha
         std::unordered_map<std::string, uint64_t> weight;

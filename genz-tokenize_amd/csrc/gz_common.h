@@ -121,8 +121,12 @@ GZ_HD uint32_t gz_word_hash2(const uint64_t k[4], uint32_t len)
 }
 
 // Whole-word table of the big pipeline's word kernel: words of <= 16 bytes (99.4 % of running text) in 32-byte slots,
-// perfectly hashed: key bytes 0..7, 8..15 (zero padded), meta = len:5 | id << 5 (0: empty).  One 128-byte line per probe.
-struct GzWordSlot1 { uint64_t lo, hi; uint32_t meta; uint32_t pad[3]; };
+// perfectly hashed: key bytes 0..11 (zero padded), meta = len:5 | id << 5 (0: empty), key bytes 12..15.  The FIRST 16 bytes of
+// a slot answer a word of <= 12 bytes (97 % of the probes): one 16-byte load per lane; only lanes with a longer word load the
+// slot's fifth dword (a wave's scattered loads cost the CU's L1 a look-up per lane and load: 128 per round before, ~ 67 now).
+struct GzWordSlot1 { uint32_t k[3]; uint32_t meta; uint32_t k3; uint32_t pad[3]; };
+GZ_HD uint64_t gz_slot1_lo(const GzWordSlot1& e) { return (uint64_t)e.k[0] | ((uint64_t)e.k[1] << 32); }
+GZ_HD uint64_t gz_slot1_hi(const GzWordSlot1& e) { return (uint64_t)e.k[2] | ((uint64_t)e.k3 << 32); }
 // the two hashes of such a key
 GZ_HD uint32_t gz_word1_ha(uint64_t lo, uint64_t hi, uint32_t len, uint32_t k1, uint32_t k2)
 {
