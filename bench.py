@@ -41,8 +41,8 @@ import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X HBM3E spec peak (MI355X_MICROARCH.md, chip-level parameters)
 N_SHARDS, SHARD_DOCS, SHARD_SEED0 = 8, 1_250_000, 100
-PIPELINE = ("gz_brk, gz_classify, gz_scan32, gz_docw0, gz_words2, gz_scan32 (misses), gz_mpre, gz_miss2 || gz_miss_wide + gz_long "
-            "(side stream), gz_rows1")
+PIPELINE = ("gz_classify, gz_scan32, gz_words2, gz_scan32 (misses), gz_mpre, gz_miss2 || gz_docw0 + gz_miss_wide + gz_long "
+            "(side stream; gz_brk and the clears of the NEXT launch follow there, under gz_rows1), gz_rows1")
 
 
 def kernel_source_sha16():

@@ -116,6 +116,7 @@ struct gz_ctx {
     uint32_t lb_epoch = 0;               // call number of the chained scan (gz_split_kernel)   // [slot][text]
     hipStream_t stream2 = nullptr;       // sub-batches alternate between the two streams
     hipStream_t side = nullptr;          // the wide-word kernels of a text run here, beside the merge kernel
+    bool flags_lazy = false;       // the device flags of the pending chain have not been copied to h_flags yet (sync_locked does it)
     bool caller_buffers = false;   // set by the device entry points around encode_device_locked: text / offsets are the caller's
                                    // own device buffers (readable now), not staging copies queued on the stream
     hipEvent_t ev_sf0[2][2] = {}, ev_sf[2][2] = {}, ev_sj[2][2] = {}, ev_sb[2][2] = {};    // [slot][text]: forks / joins of the side stream
@@ -221,9 +222,14 @@ int enqueue(gz_ctx* c)
     // [0] scan time-out, [1] capacity error, [3] a word needs the wide / long kernels.  Calls chained without a host
     // synchronisation keep [0]: it is only cleared when a chain starts, so a time-out in ANY call of the chain is still
     // there when the chain is closed (sync_locked)
+    // A dense call uses [0] and [3] only, and both may stay as they are inside a chain: [0] is meant to, and a stale [3] only
+    // keeps gz_long_kernel from leaving at once (its list is empty).  Such a call neither clears the flags inside a chain nor
+    // copies them back: the copy is made once, when the chain is closed (sync_locked) -- between two launches that follow each
+    // other the stream then has nothing to do but the next launch (each clear / copy is a kernel of its own: ~ 10 us of idle chip).
+    const bool lazy_flags = !no_flags && !p.ragged;
     if (!no_flags) {
-        if (p.chained) HIPCHK(c, hipMemsetAsync((int32_t*)c->w_flags.p + 1, 0, 12, s));
-        else HIPCHK(c, hipMemsetAsync(c->w_flags.p, 0, 16, s));
+        if (!p.chained) HIPCHK(c, hipMemsetAsync(c->w_flags.p, 0, 16, s));
+        else if (!lazy_flags) HIPCHK(c, hipMemsetAsync((int32_t*)c->w_flags.p + 1, 0, 12, s));
     }
     if (p.timing) {
         hipEvent_t* slot = c->ring[c->ring_n % gz_ctx::RING];
@@ -252,7 +258,8 @@ int enqueue(gz_ctx* c)
     if (p.timing) HIPCHK(c, hipEventRecord(c->ev[2], s));
     if (p.pair) gz_launch_pair(c->dev, p.P, s);
     if (p.timing) HIPCHK(c, hipEventRecord(c->ev[3], s));
-    if (!no_flags) HIPCHK(c, hipMemcpyAsync(c->h_flags, c->w_flags.p, 8, hipMemcpyDeviceToHost, s));
+    if (lazy_flags) c->flags_lazy = true;
+    else if (!no_flags) { HIPCHK(c, hipMemcpyAsync(c->h_flags, c->w_flags.p, 8, hipMemcpyDeviceToHost, s)); c->flags_lazy = false; }
     else if (!p.chained) c->h_flags[0] = c->h_flags[1] = 0;
     HIPCHK(c, hipEventRecord(c->ev_tok[c->enc_seq & 3], s));
     c->enc_seq++;
@@ -276,6 +283,10 @@ int x_end(gz_ctx* c)
 
 int sync_locked(gz_ctx* c)
 {
+    if (c->flags_lazy) {                                         // the flags of a chain of dense calls: copied once, now
+        c->flags_lazy = false;
+        HIPCHK(c, hipMemcpyAsync(c->h_flags, c->w_flags.p, 8, hipMemcpyDeviceToHost, c->stream));
+    }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->x_used) HIPCHK(c, hipStreamSynchronize(c->xstream));
     gz_ctx::Pending& p = c->pend;
