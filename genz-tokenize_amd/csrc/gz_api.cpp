@@ -95,6 +95,7 @@ struct gz_ctx {
         const uint8_t* s_pair0 = nullptr; const int64_t* s_poff = nullptr; int64_t s_pbase = 0;
         int32_t s_max_len = 0; int32_t* s_ids = nullptr; int32_t* s_mask = nullptr; int32_t* s_nreal = nullptr; int32_t* s_arena = nullptr;
         bool keep_words = false;
+        int t_slot = 0;                // timing: the call's pair of events in the ring
         bool chained = false;          // enqueued behind a call that has not been synchronised (its scan flag is kept)
         bool inputs_resident = false;  // the caller's device buffers are readable now (no copy of them is queued on the stream)
     } pend;
@@ -234,7 +235,8 @@ int enqueue(gz_ctx* c)
     if (p.timing) {
         hipEvent_t* slot = c->ring[c->ring_n % gz_ctx::RING];
         if (!slot[0]) { HIPCHK(c, hipEventCreate(&slot[0])); HIPCHK(c, hipEventCreate(&slot[1])); }
-        HIPCHK(c, hipEventRecord(c->ev[0], s)); HIPCHK(c, hipEventRecord(slot[0], s));
+        HIPCHK(c, hipEventRecord(slot[0], s));                  // (one timed event at each end of the kernels: every one costs the
+                                                                //  stream ~ 5 us between two launches)
     }
     const bool two = p.subs.size() > 1;
     if (two) { HIPCHK(c, hipEventRecord(c->ev_fork, s)); HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0)); }
@@ -250,14 +252,14 @@ int enqueue(gz_ctx* c)
         gz_launch_assemble(T, S, sk);
     }
     if (two) { HIPCHK(c, hipEventRecord(c->ev_join, c->stream2)); HIPCHK(c, hipStreamWaitEvent(s, c->ev_join, 0)); }
-    if (p.timing) { HIPCHK(c, hipEventRecord(c->ev[1], s)); HIPCHK(c, hipEventRecord(c->ring[c->ring_n % gz_ctx::RING][1], s)); c->ring_n++; }
+    if (p.timing) { p.t_slot = (int)(c->ring_n % gz_ctx::RING); HIPCHK(c, hipEventRecord(c->ring[p.t_slot][1], s)); c->ring_n++; }
     if (p.ragged) {
         gz_launch_rowscan(p.F, (int64_t*)c->w_rowlen.p, s);
         gz_launch_finalize(c->dev, p.F, s);
     }
-    if (p.timing) HIPCHK(c, hipEventRecord(c->ev[2], s));
+    if (p.timing && (p.ragged || p.pair)) HIPCHK(c, hipEventRecord(c->ev[2], s));      // (dense single texts: nothing follows the row kernel)
     if (p.pair) gz_launch_pair(c->dev, p.P, s);
-    if (p.timing) HIPCHK(c, hipEventRecord(c->ev[3], s));
+    if (p.timing && (p.ragged || p.pair)) HIPCHK(c, hipEventRecord(c->ev[3], s));
     if (lazy_flags) c->flags_lazy = true;
     else if (!no_flags) { HIPCHK(c, hipMemcpyAsync(c->h_flags, c->w_flags.p, 8, hipMemcpyDeviceToHost, s)); c->flags_lazy = false; }
     else if (!p.chained) c->h_flags[0] = c->h_flags[1] = 0;
@@ -293,10 +295,14 @@ int sync_locked(gz_ctx* c)
     if (!p.active) return GZ_OK;
     if (p.timing) {
         float ms = 0;
-        hipEventElapsedTime(&ms, c->ev[0], c->ev[1]); c->timing[0] = ms;
-        hipEventElapsedTime(&ms, c->ev[1], c->ev[2]); c->timing[1] = ms;
-        hipEventElapsedTime(&ms, c->ev[2], c->ev[3]); c->timing[2] = ms;
-        hipEventElapsedTime(&ms, c->ev[0], c->ev[3]); c->timing[3] = ms;
+        hipEvent_t t0 = c->ring[p.t_slot][0], t1 = c->ring[p.t_slot][1];
+        hipEventElapsedTime(&ms, t0, t1); c->timing[0] = ms;
+        c->timing[1] = c->timing[2] = 0; c->timing[3] = ms;
+        if (p.ragged || p.pair) {
+            hipEventElapsedTime(&ms, t1, c->ev[2]); c->timing[1] = ms;
+            hipEventElapsedTime(&ms, c->ev[2], c->ev[3]); c->timing[2] = ms;
+            hipEventElapsedTime(&ms, t0, c->ev[3]); c->timing[3] = ms;
+        }
     }
     p.active = false;
     if (c->h_flags[0]) return fail(c, GZ_E_HIP, "internal: a chained scan (gz_scan32m_kernel / gz_split_kernel look-back) timed out");

@@ -21,7 +21,7 @@ c0 = ctxs[0]
 d_text = c0.alloc(len(text) + 64); c0.h2d(d_text, text)
 d_off = c0.alloc(8 * (n + 1)); c0.h2d(d_off, offs)
 outs = [(c0.alloc(4 * n * L), c0.alloc(4 * n * L), c0.alloc(4 * n)) for _ in range(2)]
-flags = _native.GZ_PADDING | _native.GZ_TRUNCATION
+flags = _native.GZ_PADDING | _native.GZ_TRUNCATION | (_native.GZ_TIMING if os.environ.get("TIMING") else 0)
 hoff = np.ascontiguousarray(offs, dtype=np.int64)
 
 def run(nctx):
