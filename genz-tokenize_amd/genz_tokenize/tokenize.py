@@ -481,5 +481,7 @@ class Tokenize(object):
 
 
 def get_pairs(word):
-    """tokenize.py:270-278: the set of adjacent symbol pairs of a word tuple."""
+    """tokenize.py:270-278: the set of adjacent symbol pairs of a word (a tuple of symbols, or a str).  An empty word
+    raises IndexError as the reference's `word[0]` does (:272)."""
+    word[0]
     return {(a, b) for a, b in zip(word, word[1:])}

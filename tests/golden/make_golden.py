@@ -107,6 +107,27 @@ def g1(tok):
         rows.append({"kind": "bpe", "word": "", "raises": type(e).__name__})
     for w in [("a", "b", "c"), ("a",), ("a", "a", "a")]:
         rows.append({"kind": "get_pairs", "word": list(w), "result": sorted(list(p) for p in get_pairs(w))})
+    # edge rows of the public helpers (tokenize.py:154-182, :270-278): empty / one element / no eos, raises recorded
+    def rec(fn, *a):
+        try:
+            return {"result": fn(*a)}
+        except Exception as e:  # noqa: BLE001
+            return {"raises": type(e).__name__, "msg": str(e)}
+    for w in [(), ("a",), ("a", "b"), ("ab", "ab", "ab", "c"), "abc", ""]:
+        r = rec(get_pairs, w)
+        if "result" in r:
+            r["result"] = sorted(list(q) for q in r["result"])
+        rows.append({"kind": "get_pairs_edge", "word": list(w) if isinstance(w, tuple) else w, "is_str": isinstance(w, str), **r})
+    for ids in ([], [1], [2], [1, 2], [5, 6, 7], [1, 5, 6], [1, 5, 2], [1, 2, 2, 2], [1, 5, 2, 2, 6, 7, 2, 0, 0],
+                [1, 5, 2, 2, 2, 0, 0], [1, 5, 2, 6, 2, 7, 2], [2, 2, 2, 2], [1, 1, 2, 1, 2], [0, 0, 0]):
+        rows.append({"kind": "get_sequence_id", "ids": ids, **rec(tok.get_sequence_id, list(ids))})
+    for seq in ([], [None], [None, None], [None, 0, None], [None, 0, None, None, 1, None], [0, 0, 0, 0],
+                [None, 0, 0, None, None, 1, 1, None, 1, 1], [None, None, None, None], [5, None, 7, None, 9]):
+        arg = list(seq)
+        r = rec(tok.get_token_type, arg)
+        rows.append({"kind": "get_token_type", "seq": seq, "after": arg, **r})      # `after`: the argument as the call left it (in place)
+    for ids in ([], [0], [1, 0, 5, 0], [7, 7]):
+        rows.append({"kind": "get_atttention_mask", "ids": ids, **rec(tok.get_atttention_mask, list(ids))})
     rows.append({"kind": "vocab_size", "result": tok.vocab_size()})
     rows.append({"kind": "helpers", "ids": [1, 5, 0, 2, 0],
                  "attention_mask": tok.get_atttention_mask([1, 5, 0, 2, 0]),

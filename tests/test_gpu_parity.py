@@ -71,6 +71,26 @@ def test_g1_cases(tok):
         elif k == "helpers":
             assert tok.get_atttention_mask(row["ids"]) == row["attention_mask"]
             assert tok.get_sequence_id([1, 5, 2, 2, 6, 2, 0]) == row["sequence_id"]
+        elif k in ("get_pairs", "get_pairs_edge"):
+            from genz_tokenize.tokenize import get_pairs
+            w = row["word"] if row.get("is_str") else tuple(row["word"])
+            if "raises" in row:
+                with pytest.raises(IndexError):
+                    get_pairs(w)
+            else:
+                assert sorted(list(q) for q in get_pairs(w)) == row["result"]
+        elif k == "get_sequence_id":
+            assert tok.get_sequence_id(list(row["ids"])) == row["result"]
+        elif k == "get_token_type":
+            arg = list(row["seq"])
+            if "raises" in row:
+                with pytest.raises({"ValueError": ValueError, "IndexError": IndexError}[row["raises"]]):
+                    tok.get_token_type(arg)
+            else:
+                assert tok.get_token_type(arg) == row["result"]
+            assert arg == row["after"]
+        elif k == "get_atttention_mask":
+            assert tok.get_atttention_mask(list(row["ids"])) == row["result"]
     assert n >= 45
 
 

@@ -4,6 +4,7 @@ import base64
 import hashlib
 import json
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -55,6 +56,18 @@ def test_g1_cases(oracle_tables):
         elif k == "helpers":
             assert [1 if v != t.pad_id else 0 for v in row["ids"]] == row["attention_mask"]
             assert O.sequence_id([1, 5, 2, 2, 6, 2, 0], t.bos_id, t.eos_id) == row["sequence_id"]
+        elif k == "get_sequence_id":
+            assert O.sequence_id(row["ids"], t.bos_id, t.eos_id) == row["result"]
+        elif k == "get_token_type":
+            arg = list(row["seq"])
+            if "raises" in row:
+                with pytest.raises({"ValueError": ValueError, "IndexError": IndexError}[row["raises"]]):
+                    O.token_type_inplace(arg)
+            else:
+                assert O.token_type_inplace(arg) == row["result"]
+            assert arg == row["after"]                                   # in place, also when it raises half-way
+        elif k == "get_atttention_mask":
+            assert [1 if v != t.pad_id else 0 for v in row["ids"]] == row["result"]
         n += 1
     assert n >= 70
 
@@ -151,3 +164,22 @@ def test_g5_hash_first_blocks(oracle_tables):
         if e["block"] <= 2500:
             hi, hm, _ = _block_hashes(oracle_tables, text, offs, L, 0, e["block"])
             assert hi == e["ids_sha256"][0] and hm == e["mask_sha256"][0], name
+
+
+def test_g1_get_pairs_module_function():
+    """The drop-in's module function get_pairs (tokenize.py:270-278) against the reference's recorded results, including
+    the IndexError on an empty word.  Needs no GPU: importing the package does not load the library."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "genz-tokenize_amd"))
+    from genz_tokenize.tokenize import get_pairs
+    n = 0
+    for row in read_jsonl("g1_cases.jsonl"):
+        if row["kind"] not in ("get_pairs", "get_pairs_edge"):
+            continue
+        w = row["word"] if row.get("is_str") else tuple(row["word"])
+        if "raises" in row:
+            with pytest.raises(IndexError):
+                get_pairs(w)
+        else:
+            assert sorted(list(q) for q in get_pairs(w)) == row["result"]
+        n += 1
+    assert n >= 9

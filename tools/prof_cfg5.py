@@ -1,0 +1,34 @@
+#!/usr/bin/env python3
+"""Driver for rocprofv3 on BASELINE configs[4]: Tokenize.fromFile custom tables (100 000-entry vocab, header-less merges),
+50 000 documents of <= 4 000 characters, max_len = 1024 pad + trunc, through the device entry point.  No torch.
+usage: prof_cfg5.py [iters]"""
+import os
+import sys
+import tempfile
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "genz-tokenize_amd"))
+import numpy as np
+import corpus
+from genz_tokenize import Tokenize, _native
+
+iters = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+v, b = corpus.custom_tables()
+tmp = tempfile.mkdtemp()
+open(os.path.join(tmp, "v"), "wb").write(v); open(os.path.join(tmp, "b"), "wb").write(b)
+tok = Tokenize.fromFile(os.path.join(tmp, "v"), os.path.join(tmp, "b")); tok._sync_tables(); ctx = tok._ctx
+text, offs, L = corpus.config_corpus(5)
+text = np.ascontiguousarray(text); offs = np.ascontiguousarray(offs, dtype=np.int64)
+n = len(offs) - 1
+d_text = ctx.alloc(len(text) + 64); ctx.h2d(d_text, text)
+d_off = ctx.alloc(8 * (n + 1)); ctx.h2d(d_off, offs)
+d_ids = ctx.alloc(4 * n * L); d_mask = ctx.alloc(4 * n * L); d_nreal = ctx.alloc(4 * n)
+flags = _native.GZ_PADDING | _native.GZ_TRUNCATION | _native.GZ_TIMING
+ms = []
+for _ in range(iters):
+    ctx.encode_device(d_text, d_off, 0, 0, n, L, flags, n * L, d_ids, d_mask, d_n_real=d_nreal)
+    ctx.sync()
+    ms.append(ctx.timing()[0])
+nr = np.empty(n, dtype=np.int32); ctx.d2h(nr, d_nreal)
+print("docs", n, "bytes", len(text), "tokens", int(nr.sum()), "kernel ms", [round(x, 3) for x in ms],
+      "MB/s", round(len(text) / min(ms) / 1e3, 1))
