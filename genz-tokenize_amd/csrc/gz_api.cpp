@@ -110,9 +110,9 @@ struct gz_ctx {
     void* comm = nullptr;
     int rank = 0, world = 1;
 
-    DBuf t_words2, t_words0;
-    DBuf t_pair8, t_pair_disp, t_words0p, t_word0_disp;      // perfect-hash forms (gz_common.h)
-    DBuf t_pair_hot, t_word_hot;                             // hot sets the kernels stage in LDS
+    DBuf t_words2;                                           // long-key whole-word table (17..32 bytes)
+    DBuf t_pair8, t_pair_disp, t_words0p, t_word0_disp;      // the perfectly hashed tables (gz_common.h)
+    DBuf t_pair_hot;                                         // hot set the merge kernel stages in LDS
     struct TextWs { DBuf brk, st, en, blkcnt, docw0, wtok, waux, mtok, mlist, blkmiss, tilecnt, wlist, grpblk, lookback, mq; } tw[2][2];
     uint32_t lb_epoch = 0;               // call number of the chained scan (gz_split_kernel)   // [slot][text]
     hipStream_t stream2 = nullptr;       // sub-batches alternate between the two streams
@@ -149,7 +149,7 @@ struct gz_ctx {
     uint32_t* h_tot = nullptr;           // pinned: compact size of every sub-batch
     uint8_t* h_stage = nullptr; size_t h_stage_cap = 0;      // pinned staging of small host calls (one copy in, one copy out)
     DBuf w_stage;
-    int cache_status = 0;                // of the last gz_load_tables: 0 no cache, 1 hit, 2 miss (written), 3 a file was refused (rebuilt)
+    int cache_status = 0;                // of the last gz_load_tables: 0 no cache, 1 hit, 2 miss (written), 3 a file was refused (rebuilt, rewritten), 4 rebuilt but not written
     bool building_words = false;         // the whole-word table is being built: ignore diagnostics
     bool no_words_env = false;           // GZ_WORD_TABLE=0 in the environment
 };
@@ -385,7 +385,7 @@ int use_words_flags(gz_ctx* c, uint32_t flags)
 #else
     const int ablate = 0;
 #endif
-    const int use_words = (c->dev.words0 != nullptr && !(flags & GZ_NO_WORD_TABLE) && !c->no_words_env) ? 1 : 0;
+    const int use_words = (c->dev.words0p != nullptr && !(flags & GZ_NO_WORD_TABLE) && !c->no_words_env) ? 1 : 0;
     return use_words | (ablate << 8);
 }
 
@@ -576,9 +576,8 @@ static int build_word_table(gz_ctx* c, WordImages& W)
                                 ids.data(), mask.data(), nullptr, nullptr, row.data(), nullptr, nreal.data(), nullptr);
     c->building_words = false;
     if (rc) return rc;
-    std::vector<GzWordSlot2> found2;
-    std::vector<GzWordSlot0> found0;
-    std::vector<GzWordSlot1> found1;                         // <= 16 bytes: the big pipeline's table
+    std::vector<GzWordSlot2> found2;                         // 17..32 bytes: the long-key table (probed once per miss)
+    std::vector<GzWordSlot1> found1;                         // <= 16 bytes: perfectly hashed, one probe per word
     for (int64_t i = 0; i < n; ++i) {
         if (row[i + 1] - row[i] != 3) continue;
         const int32_t id = ids[row[i] + 1];
@@ -591,31 +590,14 @@ static int build_word_table(gz_ctx* c, WordImages& W)
             e1.meta = len | ((uint32_t)id << 5);
             std::memcpy(e1.k, key, 12); std::memcpy(&e1.k3, key + 12, 4);
             found1.push_back(e1);
-        }
-        if (len <= 12) {
-            GzWordSlot0 e{0, 0, len | ((uint32_t)id << 4)};
-            std::memcpy(&e.lo, key, 8); std::memcpy(&e.hi, key + 8, 4);
-            found0.push_back(e);
         } else {
             GzWordSlot2 e{{0, 0, 0, 0}, len, id, {0, 0, 0, 0, 0, 0}};
             std::memcpy(e.k, key, 32);
             found2.push_back(e);
         }
     }
-    if (found0.empty()) return GZ_OK;            // (the 13..32-byte table is only consulted for misses of the first)
+    if (found1.empty()) return GZ_OK;            // (the long-key table is only consulted for misses of the first)
     {
-        size_t slots0 = 16;
-        while (slots0 < gz_tab_slack() * found0.size()) slots0 <<= 1;
-        std::vector<GzWordSlot0>& tab0 = W.tab0;
-        tab0.assign(slots0, GzWordSlot0{0, 0, 0});
-        for (const GzWordSlot0& e : found0) {
-            size_t h = gz_word_hash0(e.lo, e.hi, e.meta & 15u) & (slots0 - 1);
-            while (tab0[h].meta != 0) h = (h + 1) & (slots0 - 1);
-            tab0[h] = e;
-        }
-    }
-    {
-        // the words of <= 16 bytes, perfectly hashed (the big pipeline's word kernel: one line per probe, gz_common.h)
         std::vector<uint32_t> hb(found1.size()), slot_of;
         for (size_t i = 0; i < found1.size(); ++i) hb[i] = gz_word1_hb(gz_slot1_lo(found1[i]), gz_slot1_hi(found1[i]), found1[i].meta & 31u);
         auto ha = [](const void* ctx, size_t i, uint32_t k1, uint32_t k2) -> uint32_t {
@@ -626,28 +608,6 @@ static int build_word_table(gz_ctx* c, WordImages& W)
         gz_ph_build(found1.size(), ha, &found1, hb.data(), ph, slot_of);
         W.tabp.assign(ph.slots, GzWordSlot1{});
         for (size_t i = 0; i < found1.size(); ++i) W.tabp[slot_of[i]] = found1[i];
-        // hot set: the words the vocab file counts most often (no counts: the file's order), direct-mapped by the top bits of ha
-        std::unordered_map<std::string, uint64_t> weight;
-        {
-            bool any = false;
-            for (uint64_t h : H.enc_hint) if (h) { any = true; break; }
-            for (size_t i = 0; i < H.enc_words.size(); ++i) weight[H.enc_words[i]] = any ? H.enc_hint[i] : (uint64_t)(H.enc_words.size() - i);
-        }
-        std::vector<std::pair<uint64_t, uint32_t>> order(found0.size());
-        for (size_t i = 0; i < found0.size(); ++i) {
-            char key[12];
-            std::memcpy(key, &found0[i].lo, 8); std::memcpy(key + 8, &found0[i].hi, 4);
-            auto it = weight.find(std::string(key, found0[i].meta & 15u));
-            order[i] = {it == weight.end() ? 0 : it->second, (uint32_t)i};
-        }
-        std::sort(order.begin(), order.end(), [](const std::pair<uint64_t, uint32_t>& x, const std::pair<uint64_t, uint32_t>& y) { return x.first != y.first ? x.first > y.first : x.second < y.second; });
-        std::vector<GzWordSlot0>& hot = W.hot;
-        hot.assign(GZ_WORD_HOT_SLOTS, GzWordSlot0{0, 0, 0});
-        for (const auto& o : order) {
-            const GzWordSlot0& e = found0[o.second];
-            GzWordSlot0& h = hot[gz_word1_ha(e.lo, e.hi, e.meta & 15u, ph.k1, ph.k2) >> GZ_WORD_HOT_SHIFT];
-            if (h.meta == 0) h = e;
-        }
     }
     if (!found2.empty()) {
         size_t slots2 = 16;
@@ -660,7 +620,7 @@ static int build_word_table(gz_ctx* c, WordImages& W)
             tab2[h] = e;
         }
     }
-    W.n_words = (int64_t)(found0.size() + found2.size());
+    W.n_words = (int64_t)(found1.size() + found2.size());
     return GZ_OK;
 }
 
@@ -669,17 +629,13 @@ static int install_word_tables(gz_ctx* c, const WordImages& W)
 {
     int rc;
     if (W.tabp.empty()) return GZ_OK;
-    if ((rc = upload(c, c->t_words0, W.tab0)) || (rc = upload(c, c->t_words0p, W.tabp)) || (rc = upload(c, c->t_word0_disp, W.ph.disp)) ||
-        (rc = upload(c, c->t_word_hot, W.hot)))
-        return rc;
+    if ((rc = upload(c, c->t_words0p, W.tabp)) || (rc = upload(c, c->t_word0_disp, W.ph.disp))) return rc;
     if (!W.tab2.empty() && (rc = upload(c, c->t_words2, W.tab2))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));                  // (the images may die once this returns)
     GzDeviceTables& D = c->dev;
-    D.words0 = (const GzWordSlot0*)c->t_words0.p; D.word0_mask = (uint32_t)W.tab0.size() - 1;
     D.words0p = (const GzWordSlot1*)c->t_words0p.p;
     D.word0_ph = GzPh{(const uint16_t*)c->t_word0_disp.p, W.ph.nbuckets, W.ph.bshift, W.ph.sshift, W.ph.slots - 1, W.ph.k1, W.ph.k2};
     D.word0_ovf = W.ph.n_overflow;
-    D.word_hot = (const GzWordSlot0*)c->t_word_hot.p;
     if (!W.tab2.empty()) { D.words2 = (const GzWordSlot2*)c->t_words2.p; D.word2_mask = (uint32_t)W.tab2.size() - 1; }
     HIPCHK(c, hipMemcpy(c->t_struct.p, &c->dev, sizeof(GzDeviceTables), hipMemcpyHostToDevice));
     c->n_words = W.n_words;
@@ -764,8 +720,8 @@ void gz_destroy(gz_ctx* c)
     for (DBuf* b : {&c->w_pp[0], &c->w_pp[1], &c->w_ppoff[0], &c->w_ppoff[1], &c->w_pplen, &c->w_ppaux, &c->w_pp_in, &c->w_pp_inoff}) release(*b);
     for (DBuf* b : {&c->t_dec_entries, &c->t_dec_bytes, &c->w_dec_ids, &c->w_dec_roff, &c->w_dec_rb, &c->w_dec_ooff, &c->w_dec_out}) release(*b);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
-    for (DBuf* b : {&c->t_pair8, &c->t_pair_disp, &c->t_words0p, &c->t_word0_disp, &c->t_pair_hot, &c->t_word_hot}) release(*b);
-    for (DBuf* b : {&c->t_pair, &c->t_merges, &c->t_symids, &c->t_bmp, &c->t_astral, &c->t_struct, &c->t_words2, &c->t_words0, &c->w_text, &c->w_toff, &c->w_pair,
+    for (DBuf* b : {&c->t_pair8, &c->t_pair_disp, &c->t_words0p, &c->t_word0_disp, &c->t_pair_hot}) release(*b);
+    for (DBuf* b : {&c->t_merges, &c->t_symids, &c->t_bmp, &c->t_astral, &c->t_struct, &c->t_words2, &c->w_text, &c->w_toff, &c->w_pair,
                     &c->w_poff, &c->w_ids, &c->w_mask, &c->w_tt, &c->w_seq, &c->w_rowoff, &c->w_rowlen, &c->w_pairlen,
                     &c->w_nreal, &c->w_status, &c->w_raw, &c->w_arena, &c->w_flags, &c->w_word, &c->w_wordout})
         release(*b);
@@ -804,7 +760,7 @@ int gz_load_tables(gz_ctx* c, const uint8_t* vocab, size_t vocab_len, const uint
         if (!cdir.empty()) {
             cache_key(vocab, vocab_len, bpe, bpe_len, specials, key);
             cpath = cache_file(cdir, key);
-            const int got = cache_read(cpath, key, c->host, W);
+            const int got = cache_dir_usable(cdir, false) ? cache_read(cpath, key, c->host, W) : 0;
             hit = got == 1;
             c->cache_status = got == 1 ? 1 : got < 0 ? 3 : 2;      // 1 hit, 2 miss, 3 a file was there and was refused
         }
@@ -816,7 +772,6 @@ int gz_load_tables(gz_ctx* c, const uint8_t* vocab, size_t vocab_len, const uint
     }
     if (rc) return rc;
     GzHostTables& H = c->host;
-    if ((rc = upload(c, c->t_pair, H.pair_tab))) return rc;
     if ((rc = upload(c, c->t_merges, H.merges))) return rc;
     if ((rc = upload(c, c->t_symids, H.sym_ids))) return rc;
     if ((rc = upload(c, c->t_bmp, H.bmp))) return rc;
@@ -824,22 +779,18 @@ int gz_load_tables(gz_ctx* c, const uint8_t* vocab, size_t vocab_len, const uint
     if ((rc = upload(c, c->t_pair8, H.pair8)) || (rc = upload(c, c->t_pair_disp, H.pair_ph.disp)) || (rc = upload(c, c->t_pair_hot, H.pair_hot))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     GzDeviceTables& D = c->dev;
-    D.pair_tab = (const GzPairSlot*)c->t_pair.p;   D.pair_mask = (uint32_t)H.pair_tab.size() - 1;
-    D.pair_shift = 32; while ((size_t(1) << (32 - D.pair_shift)) < H.pair_tab.size()) --D.pair_shift;
-    D.pair_pad = 0;
     D.merges = (const GzMergeInfo*)c->t_merges.p; D.n_ranks = (uint32_t)H.merges.size();
     D.sym_ids = (const GzSymIds*)c->t_symids.p;  D.n_symbols = (uint32_t)H.symbols.size();
     D.bmp = (const GzCpSyms*)c->t_bmp.p;
     D.astral = H.astral.empty() ? nullptr : (const GzAstral*)c->t_astral.p;
     D.astral_mask = H.astral.empty() ? 0 : (uint32_t)H.astral.size() - 1;
     D.pad_id = H.special_ids[0]; D.bos_id = H.special_ids[1]; D.eos_id = H.special_ids[2]; D.unk_id = H.special_ids[4];
-    D.words2 = nullptr; D.word2_mask = 0; D.words0 = nullptr; D.word0_mask = 0;
+    D.words2 = nullptr; D.word2_mask = 0;
     D.pair8 = (const GzPair8*)c->t_pair8.p;
     D.pair_ph = GzPh{(const uint16_t*)c->t_pair_disp.p, H.pair_ph.nbuckets, H.pair_ph.bshift, H.pair_ph.sshift, H.pair_ph.slots - 1, H.pair_ph.k1, H.pair_ph.k2};
     D.words0p = nullptr; D.word0_ph = GzPh{nullptr, 16, 28, 28, 15, 1, 1};
     D.pair_ovf = H.pair_ph.n_overflow; D.word0_ovf = 0;
     D.pair_hot = (const GzPair8*)c->t_pair_hot.p; D.pair_hot_shift = GZ_PAIR_HOT_SHIFT;
-    D.word_hot = nullptr; D.word_hot_shift = GZ_WORD_HOT_SHIFT;
     if (c->host.enc_words.size() >= (1u << 26)) return fail(c, GZ_E_LIMIT, "vocab has 2^26 or more entries");
     if ((rc = ensure(c, c->t_struct, sizeof(GzDeviceTables)))) return rc;
     HIPCHK(c, hipMemcpy(c->t_struct.p, &c->dev, sizeof(GzDeviceTables), hipMemcpyHostToDevice));
@@ -851,7 +802,9 @@ int gz_load_tables(gz_ctx* c, const uint8_t* vocab, size_t vocab_len, const uint
     rc = install_word_tables(c, W);
     if (rc) { c->have_tables = false; return rc; }
     if (!hit && !cpath.empty()) {
-        try { cache_write(cdir, cpath, key, c->host, W); } catch (...) { /* a cache that cannot be written is only a slower start */ }
+        bool written = false;
+        try { written = cache_write(cdir, cpath, key, c->host, W); } catch (...) { /* a cache that cannot be written is only a slower start */ }
+        if (!written) c->cache_status = 4;                       // 4: rebuilt, and the file could NOT be written (directory missing / shared / full)
     }
     return GZ_OK;
 }
@@ -884,21 +837,19 @@ int gz_table_digest(gz_ctx* c, uint8_t out[32])
     const GzDeviceTables& D = c->dev;
     const GzHostTables& H = c->host;
     int rc;
-    if ((rc = add(D.pair_tab, ((size_t)D.pair_mask + 1) * sizeof(GzPairSlot))) || (rc = add(D.merges, (size_t)D.n_ranks * sizeof(GzMergeInfo))) ||
+    if ((rc = add(D.merges, (size_t)D.n_ranks * sizeof(GzMergeInfo))) ||
         (rc = add(D.sym_ids, (size_t)D.n_symbols * sizeof(GzSymIds))) || (rc = add(D.bmp, 65536 * sizeof(GzCpSyms))) ||
         (rc = add(D.astral, D.astral ? ((size_t)D.astral_mask + 1) * sizeof(GzAstral) : 0)) ||
         (rc = add(D.pair8, ((size_t)D.pair_ph.mask + 1) * sizeof(GzPair8))) || (rc = add(D.pair_ph.disp, (size_t)D.pair_ph.nbuckets * 2)) ||
         (rc = add(D.pair_hot, GZ_PAIR_HOT_SLOTS * sizeof(GzPair8))) ||
-        (rc = add(D.words0, D.words0 ? ((size_t)D.word0_mask + 1) * sizeof(GzWordSlot0) : 0)) ||
         (rc = add(D.words2, D.words2 ? ((size_t)D.word2_mask + 1) * sizeof(GzWordSlot2) : 0)) ||
         (rc = add(D.words0p, D.words0p ? ((size_t)D.word0_ph.mask + 1) * sizeof(GzWordSlot1) : 0)) ||
-        (rc = add(D.word0_ph.disp, D.words0p ? (size_t)D.word0_ph.nbuckets * 2 : 0)) ||
-        (rc = add(D.word_hot, D.word_hot ? GZ_WORD_HOT_SLOTS * sizeof(GzWordSlot0) : 0)))
+        (rc = add(D.word0_ph.disp, D.words0p ? (size_t)D.word0_ph.nbuckets * 2 : 0)))
         return rc;
-    const uint32_t scal[] = {D.pair_mask, D.pair_shift, D.n_ranks, D.n_symbols, D.astral_mask, (uint32_t)D.pad_id, (uint32_t)D.bos_id, (uint32_t)D.eos_id,
-                             (uint32_t)D.unk_id, D.word0_mask, D.word2_mask, D.pair_ph.nbuckets, D.pair_ph.bshift, D.pair_ph.sshift, D.pair_ph.mask,
+    const uint32_t scal[] = {D.n_ranks, D.n_symbols, D.astral_mask, (uint32_t)D.pad_id, (uint32_t)D.bos_id, (uint32_t)D.eos_id,
+                             (uint32_t)D.unk_id, D.word2_mask, D.pair_ph.nbuckets, D.pair_ph.bshift, D.pair_ph.sshift, D.pair_ph.mask,
                              D.pair_ph.k1, D.pair_ph.k2, D.word0_ph.nbuckets, D.word0_ph.bshift, D.word0_ph.sshift, D.word0_ph.mask, D.word0_ph.k1,
-                             D.word0_ph.k2, D.pair_ovf, D.word0_ovf, D.pair_hot_shift, D.word_hot_shift};
+                             D.word0_ph.k2, D.pair_ovf, D.word0_ovf, D.pair_hot_shift};
     sha.update(scal, sizeof scal);
     // the host side of the tables (what the Python surface reads back)
     for (const std::string& w : H.enc_words) { const uint32_t l = (uint32_t)w.size(); sha.update(&l, 4); sha.update(w.data(), l); }

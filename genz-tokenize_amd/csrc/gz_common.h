@@ -27,26 +27,19 @@ constexpr uint32_t GZ_NO_SYMBOL   = 0xFFFFFFFFu;      // table entry: code point
 constexpr uint32_t GZ_RANK_NONE   = 0xFFFFFFFFu;      // "pair is not in bpe_ranks" (the float('inf') of tokenize.py:71)
 constexpr uint32_t GZ_PAIR_EMPTY  = 0xFFFFFFFFu;      // `left` of an empty pair slot
 
-// pair -> rank hash table entry: GzPairSlot {left, right, merged, rank} below (16 bytes, 32-bit compares only)
-// slot of the pair (a, b) in a table of 2^(32 - shift) slots: multiplicative hashing, the TOP bits of one multiply-add
-// (three VALU instructions in the merge loop, which runs one probe per iteration)
-GZ_HD uint32_t gz_pair_slot(uint32_t a, uint32_t b, uint32_t shift) { return (a * 0x9E3779B1u + b * 0x85EBCA6Bu) >> shift; }
 GZ_HD uint32_t gz_cp_hash(uint32_t cp)
 {
     uint32_t h = cp * 0x9E3779B1u;
     return h ^ (h >> 16);
 }
 
-// Hash tables (pair table, whole-word tables): slots >= GZ_TAB_SLACK x entries, rounded up to a power of two.  A wave
-// probes 64 keys at once and loops until its LAST lane is done, so the tail of the probe-length distribution is what
-// costs.  Measured (us per launch of 1 M documents) for 2 / 4 / 8 / 16 / 32: word kernel 416 / 374 / 369 / 346 / 361,
-// merge kernel 494 / 400 / 369 / 354 / 357.
+// The long-key whole-word table (words of 17..32 bytes, probed once per MISS) is a plain open-addressing table: slots >=
+// GZ_TAB_SLACK x entries, rounded up to a power of two.  (The environment variable GZ_TAB_SLACK = 2 .. 64 overrides it when
+// the tables are built: the parity suite runs its golden batches once more at half load, where probe chains are long, so
+// that the continue-probing paths stay exercised.)
 #ifndef GZ_TAB_SLACK
 #define GZ_TAB_SLACK 16
 #endif
-// (the environment variable GZ_TAB_SLACK = 2 .. 64 overrides it when the tables are built: the parity suite runs its
-// golden batches once more on tables at half load, where probe chains are long, so that the continue-probing paths of the
-// kernels stay exercised)
 inline size_t gz_tab_slack()
 {
     static const size_t v = [] {
@@ -56,7 +49,6 @@ inline size_t gz_tab_slack()
     }();
     return v;
 }
-struct GzPairSlot  { uint32_t left, right, merged, rank; };              // left == GZ_PAIR_EMPTY -> empty; 32-bit compares only
 
 // ---------------------------------------------------------------------------------------------------------
 // Static perfect hashing (hash and displace) for the tables the two hot kernels probe once per word / once per
@@ -73,7 +65,6 @@ constexpr uint32_t GZ_PH_MUL = 0x2C1B3C6Du;
 constexpr uint32_t GZ_PH_OVERFLOW = 0xFFFFu;
 constexpr uint32_t GZ_PH_LDS_BUCKETS = 16384;                 // displacement entries a workgroup stages in LDS (32 KB)
 constexpr uint32_t GZ_PAIR_HOT_SLOTS = 4096, GZ_PAIR_HOT_SHIFT = 20;      // 32 KB of LDS
-constexpr uint32_t GZ_WORD_HOT_SLOTS = 2048, GZ_WORD_HOT_SHIFT = 21;      // 32 KB of LDS
 struct GzPh {
     const uint16_t* disp;                                     // [nbuckets] (device copy)
     uint32_t nbuckets, bshift;                                // bucket = ha >> bshift      (nbuckets = 2^(32 - bshift) >= 16)
@@ -96,17 +87,7 @@ struct GzCpSyms    { uint32_t plain, final_; };              // symbol of  c  / 
 struct GzAstral    { uint32_t cp, plain, final_, pad; };     // open-addressing entry, cp == GZ_NO_SYMBOL -> empty
 // Whole-word tables: word bytes -> the single vocab id bpe() yields for that word.  Built at table-load time by
 // running the GPU merge path itself over every candidate word (gz_api.cpp).
-// first whole-word table: words of <= 12 bytes (96 % of running text) in 16-byte slots -> ONE 16-byte load per probe
-struct GzWordSlot0 { uint64_t lo; uint32_t hi; uint32_t meta; };        // meta = len:4 | id << 4;  0 -> empty
-GZ_HD uint32_t gz_word_hash0(uint64_t lo, uint32_t hi, uint32_t len)
-{
-    uint32_t h = (uint32_t)lo * 0x9E3779B1u ^ (uint32_t)(lo >> 32) * 0x85EBCA6Bu ^ hi * 0xC2B2AE35u ^ len * 0x165667B1u;
-    h ^= h >> 15;
-    h *= 0x2C1B3C6Du;
-    h ^= h >> 13;
-    return h;
-}
-// second whole-word table: words of 13..32 bytes (64-byte slots), probed by the miss kernel
+// long-key whole-word table: words of 17..32 bytes (64-byte slots, linear probing), probed once per miss by the merge pre-pass
 struct GzWordSlot2 { uint64_t k[4]; uint32_t len; int32_t id; uint32_t pad[6]; };    // len == 0 -> empty
 GZ_HD uint32_t gz_word_hash2(const uint64_t k[4], uint32_t len)
 {
@@ -143,23 +124,20 @@ GZ_HD uint32_t gz_word1_hb(uint64_t lo, uint64_t hi, uint32_t len)
 
 // Device-resident tables, passed to kernels by value.
 struct GzDeviceTables {
-    const GzPairSlot*  pair_tab;    uint32_t pair_mask;      // slots-1 (power of two; >= 16 slots)
-    uint32_t           pair_shift;  uint32_t pair_pad;       // 32 - log2(slots): gz_pair_slot(a, b, pair_shift)
     const GzMergeInfo* merges;      uint32_t n_ranks;
     const GzSymIds*    sym_ids;     uint32_t n_symbols;
     const GzCpSyms*    bmp;                                   // 65536 entries
     const GzAstral*    astral;      uint32_t astral_mask;    // slots-1; astral == nullptr when no astral symbol exists
     int32_t pad_id, bos_id, eos_id, unk_id;
-    const GzWordSlot0* words0;      uint32_t word0_mask;     // whole-word table, <= 12 bytes (nullptr until built)
-    const GzWordSlot2* words2;      uint32_t word2_mask;     // whole-word table, 13..32 bytes (may be nullptr)
-    // perfect-hash forms (the big pipeline's word and merge kernels)
+    const GzWordSlot2* words2;      uint32_t word2_mask;     // whole-word table, 17..32 bytes (may be nullptr)
+    // perfect-hash tables (one family for every kernel: the big pipeline stages the displacement arrays in LDS, the
+    // one-launch small-batch kernel and the wide / long word kernels read them from memory)
     const GzPair8*     pair8;       GzPh pair_ph;             // pair -> rank (= merged symbol)
     const GzWordSlot1* words0p;     GzPh word0_ph;            // whole-word table, <= 16 bytes (nullptr until built)
     uint32_t pair_ovf, word0_ovf;                             // keys in overflow buckets (0 on every real table: the kernels' fast forms)
-    // hot sets, staged in LDS by the two kernels (same entry layouts, direct-mapped, slot = top bits of ha): a probe that
-    // hits there costs no memory traffic -- a random probe of a table in L2 moves a whole 128-byte line for 8 or 16 bytes
+    // hot set of the merge kernel, staged in LDS (same entry layout, direct-mapped, slot = top bits of ha): a probe that
+    // hits there costs no memory traffic -- a random probe of a table in L2 moves a whole 128-byte line for 8 bytes
     const GzPair8*     pair_hot;    uint32_t pair_hot_shift;  // [2^(32 - shift)] the most frequent merges (smallest ranks)
-    const GzWordSlot0* word_hot;    uint32_t word_hot_shift;  // [2^(32 - shift)] the most frequent words (vocab counts / order)
 };
 
 // Host side of a perfect hash: hashes in, displacement array + the slot of every key out (gz_tables.cpp).
@@ -197,13 +175,11 @@ struct GzHostTables {
     // interned symbols
     std::vector<std::string> symbols;
     // device images
-    std::vector<GzPairSlot>  pair_tab;
     std::vector<GzMergeInfo> merges;
     std::vector<GzSymIds>    sym_ids;
     std::vector<GzCpSyms>    bmp;
     std::vector<GzAstral>    astral;     // empty when unused
-    uint32_t max_probe = 0;
-    std::vector<GzPair8>     pair8;      // perfect-hash form of pair_tab
+    std::vector<GzPair8>     pair8;      // pair -> rank, perfectly hashed
     GzPhHost                 pair_ph;
     std::vector<GzPair8>     pair_hot;   // direct-mapped hot set (GZ_PAIR_HOT_SLOTS entries)
     std::vector<uint64_t>    enc_hint;   // per encoder entry: the count the vocab line carries (0: none) -- a speed hint only

@@ -53,13 +53,13 @@ int gz_host_tables_array(gz_host_tables* t, int which, const void** data, int64_
     if (!t || !data || !count) return GZ_E_INVALID;
     GzHostTables& H = t->T;
     switch (which) {
-        case 0: *data = H.pair_tab.data(); *count = (int64_t)H.pair_tab.size(); break;
         case 1: *data = H.merges.data();   *count = (int64_t)H.merges.size(); break;
         case 2: *data = H.sym_ids.data();  *count = (int64_t)H.sym_ids.size(); break;
         case 3: *data = H.bmp.data();      *count = (int64_t)H.bmp.size(); break;
         case 4: *data = H.astral.data();   *count = (int64_t)H.astral.size(); break;
         case 5: *data = H.special_ids;     *count = 5; break;
-        // the perfect-hash form of the pair table: entries, displacement array, {nbuckets, bshift, sshift, slots, k1, k2, keys in
+        // (0 was the linear-probing pair table of rounds 1-3: gone)
+        // the pair table, perfectly hashed: entries, displacement array, {nbuckets, bshift, sshift, slots, k1, k2, keys in
         // overflow buckets}, hot set
         case 6: *data = H.pair8.data();    *count = (int64_t)H.pair8.size(); break;
         case 7: *data = H.pair_ph.disp.data(); *count = (int64_t)H.pair_ph.disp.size(); break;

@@ -69,29 +69,58 @@ __device__ __forceinline__ int wave_sum(int v)
     return v;
 }
 
-// bpe_ranks.get(pair, inf)  (tokenize.py:70-71)
-__device__ __forceinline__ uint32_t probe_rank(const GzDeviceTables& T, uint32_t a, uint32_t b)
-{
-    if ((a | b) & 0xFFF00000u) return GZ_RANK_NONE;          // a code point outside every table never merges
-    uint32_t h = gz_pair_slot(a, b, T.pair_shift);
-    for (;;) {
-        const uint4 v = *reinterpret_cast<const uint4*>(&T.pair_tab[h]);
-        if (v.x == a && v.y == b) return v.w;
-        if (v.x == GZ_PAIR_EMPTY) return GZ_RANK_NONE;
-        h = (h + 1) & T.pair_mask;
-    }
-}
-
-// the same probe returning the merged symbol too (one 16-byte load)
+// bpe_ranks.get(pair, inf) (tokenize.py:70-71) and first + second (:88) from the perfectly hashed pair table (gz_common.h): the
+// bucket's displacement (16 KB array in memory: the kernels that call this are latency-bound chains, not the big pipeline's
+// merge kernel, which stages it in LDS) -> ONE 8-byte load; the key is compared in full.  Returns the rank (GZ_RANK_NONE:
+// no such merge) and the merged symbol: the rank itself unless another line spells the same string (alias flag).
 __device__ __forceinline__ uint32_t probe_pair(const GzDeviceTables& T, uint32_t a, uint32_t b, uint32_t& merged)
 {
-    if ((a | b) & 0xFFF00000u) return GZ_RANK_NONE;
-    uint32_t h = gz_pair_slot(a, b, T.pair_shift);
+    typedef unsigned __attribute__((ext_vector_type(2))) v2u;
+    typedef const v2u __attribute__((address_space(1)))* gp8_t;
+    typedef const uint16_t __attribute__((address_space(1)))* g16_t;
+    if ((a | b) & 0xFFF00000u) return GZ_RANK_NONE;          // a code point outside every table never merges
+    const uint32_t d = ((g16_t)T.pair_ph.disp)[gz_pair_ha(a, b, T.pair_ph.k1, T.pair_ph.k2) >> T.pair_ph.bshift];
+    uint32_t h = gz_ph_slot(gz_pair_hb(a, b), d, T.pair_ph.sshift);
+    const uint32_t klo = a | (b << 20), khi = b >> 12;
+    v2u q = ((gp8_t)T.pair8)[h];
+    if (d == GZ_PH_OVERFLOW)                                  // a bucket the builder could not place: its keys sit further along
+        while (q.x != 0xFFFFFFFFu && !(q.x == klo && (q.y & 0xFFu) == khi)) {
+            h = (h + 1) & T.pair_ph.mask;
+            q = ((gp8_t)T.pair8)[h];
+        }
+    if (!(q.x == klo && (q.y & 0xFFu) == khi)) return GZ_RANK_NONE;
+    const uint32_t rank = q.y >> 9;
+    merged = (q.y & GZ_PAIR8_ALIAS) ? T.merges[rank].merged : rank;
+    return rank;
+}
+__device__ __forceinline__ uint32_t probe_rank(const GzDeviceTables& T, uint32_t a, uint32_t b)
+{
+    uint32_t merged;
+    return probe_pair(T, a, b, merged);
+}
+
+// The whole-word table of words of <= 16 bytes (perfectly hashed, gz_common.h) for the kernels that do not stage its
+// displacement array in LDS: key = the word's bytes, zero padded (lo, hi), nb bytes.  True: `id` is what bpe() + the vocab
+// lookup yield for this word (tokenize.py:62-121).
+__device__ __forceinline__ bool probe_word16(const GzDeviceTables& T, uint64_t lo, uint64_t hi, uint32_t nb, uint32_t& id)
+{
+    typedef unsigned __attribute__((ext_vector_type(4))) v4u;
+    typedef const v4u __attribute__((address_space(1)))* gw_t;
+    typedef const uint32_t __attribute__((address_space(1)))* g32_t;
+    typedef const uint16_t __attribute__((address_space(1)))* g16_t;
+    const GzPh& P = T.word0_ph;
+    const uint32_t d = ((g16_t)P.disp)[gz_word1_ha(lo, hi, nb, P.k1, P.k2) >> P.bshift];
+    uint32_t h = gz_ph_slot(gz_word1_hb(lo, hi, nb), d, P.sshift);
+    const uint8_t* tab = reinterpret_cast<const uint8_t*>(T.words0p);
     for (;;) {
-        const uint4 v = *reinterpret_cast<const uint4*>(&T.pair_tab[h]);
-        if (v.x == a && v.y == b) { merged = v.z; return v.w; }
-        if (v.x == GZ_PAIR_EMPTY) return GZ_RANK_NONE;
-        h = (h + 1) & T.pair_mask;
+        const v4u e = *(gw_t)(tab + ((size_t)h << 5));       // key bytes 0..11, len | id << 5
+        const uint32_t k3 = *(g32_t)(tab + ((size_t)h << 5) + 16);
+        if ((e.w & 31u) == nb && e.x == (uint32_t)lo && e.y == (uint32_t)(lo >> 32) && e.z == (uint32_t)hi && k3 == (uint32_t)(hi >> 32)) {
+            id = e.w >> 5;
+            return true;
+        }
+        if (d != GZ_PH_OVERFLOW || e.w == 0u) return false;    // (an overflow bucket's keys sit further along, by linear probing)
+        h = (h + 1) & P.mask;
     }
 }
 

@@ -172,8 +172,13 @@ static PyObject* gz_expand(PyObject* self, PyObject* args)
     const Py_ssize_t n = nr.len / 4;
     int ok = (bits == 16 || bits == 32) && L > 0 && row.len == (n + 1) * 8 && ids.len == (Py_ssize_t)n * L * 4 && mask.len == ids.len;
     if (ok && n > 0) {
+        /* the arrays index each other: offsets non-decreasing from 0 and inside the token buffer, every row's count >= 0 and
+         * inside its own span (an exported function: its arguments are checked, not trusted) */
         const int64_t* ro = (const int64_t*)row.buf;
-        ok = ro[0] == 0 && ro[n] * (bits / 8) <= tok.len;
+        const int32_t* nrp = (const int32_t*)nr.buf;
+        ok = ro[0] == 0 && ro[n] >= 0 && ro[n] <= tok.len / (bits / 8);
+        for (Py_ssize_t r = 0; ok && r < n; ++r)
+            ok = ro[r] <= ro[r + 1] && nrp[r] >= 0 && (int64_t)(nrp[r] < L ? nrp[r] : L) <= ro[r + 1] - ro[r];
     }
     if (ok) {
         const int nt = n_threads(n);

@@ -327,24 +327,7 @@ int gz_build_tables(const uint8_t* vocab, size_t vocab_len, const uint8_t* bpe, 
         }
     }
 
-    // ---- pair hash -------------------------------------------------------------------------------------------------
-    {
-        size_t slots = 16;
-        while (slots < gz_tab_slack() * pairs.size()) slots <<= 1;
-        uint32_t shift = 32;
-        while ((size_t(1) << (32 - shift)) < slots) --shift;
-        T.pair_tab.assign(slots, GzPairSlot{GZ_PAIR_EMPTY, 0, 0, 0});
-        uint32_t worst = 0;
-        for (const Pair& p : pairs) {
-            size_t h = gz_pair_slot(p.a, p.b, shift);
-            uint32_t probes = 1;
-            while (T.pair_tab[h].left != GZ_PAIR_EMPTY) { h = (h + 1) & (slots - 1); ++probes; }
-            T.pair_tab[h] = GzPairSlot{p.a, p.b, T.merges[p.rank].merged, p.rank};
-            worst = std::max(worst, probes);
-        }
-        T.max_probe = worst;
-    }
-    // ---- the same pairs, perfectly hashed: 8-byte entries, one load per probe ------------------------------------
+    // ---- pair -> rank, perfectly hashed: 8-byte entries, one load per probe ------------------------------------
     {
         std::vector<uint32_t> hb(pairs.size()), slot_of;
         for (size_t i = 0; i < pairs.size(); ++i) hb[i] = gz_pair_hb(pairs[i].a, pairs[i].b);

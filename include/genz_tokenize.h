@@ -34,7 +34,7 @@ extern "C" {
 #define GZ_E_HIP        -3   /* HIP runtime error */
 #define GZ_E_NOTABLES   -4   /* gz_load_tables has not succeeded on this context */
 #define GZ_E_CAPACITY   -5   /* ragged output does not fit `capacity`; row_off[n_docs] holds the size needed */
-#define GZ_E_LIMIT      -6   /* table exceeds 2^20-2 symbols or 2^23-1 merge lines */
+#define GZ_E_LIMIT      -6   /* table exceeds 2^20-2 symbol ids (every merge line takes one: merge lines + other symbols) */
 #define GZ_E_NOMEM      -7
 #define GZ_E_RCCL       -8
 #define GZ_E_NODEVICE   -9   /* no gfx950 device / HIP runtime unusable */
@@ -68,10 +68,12 @@ int  gz_load_tables(gz_ctx *ctx, const uint8_t *vocab, size_t vocab_len,
 
 /* The table cache behind gz_load_tables (reference: Tokenize.__init__ re-parses both files on every construction,
  * tokenize.py:39-42, and fromFile does so twice, :261-267).  The finished table images are kept in
- * $GZ_TABLE_CACHE (default ~/.cache/genz_tokenize_amd; "0" / "off" disables) under the SHA-256 of the file bytes, the
- * specials and the table-layout version; a file whose key, length, checksum or section sizes do not fit is refused and the
- * tables are rebuilt.  gz_table_cache_status: what the last gz_load_tables of this context did -- 0 no cache, 1 hit,
- * 2 miss (built and written), 3 a cache file was there and was refused (rebuilt and rewritten).
+ * $GZ_TABLE_CACHE (default ~/.cache/genz_tokenize_amd, created 0700; "0" / "off" disables) under the SHA-256 of the file
+ * bytes, the specials, the file-format version and the BUILD IDENTITY of this library (a hash of its sources: images made by
+ * another build are never loaded); a file whose key, length, checksum or section sizes do not fit, or that holds an index
+ * outside the tables it indexes, is refused and the tables are rebuilt; a directory other users can write to is not used.
+ * gz_table_cache_status: what the last gz_load_tables of this context did -- 0 no cache, 1 hit, 2 miss (built and written),
+ * 3 a cache file was there and was refused (rebuilt and rewritten), 4 built, but the file could not be written.
  * gz_table_digest: SHA-256 over every device table image + the host-visible dictionaries (equal for built and cached loads). */
 int  gz_table_cache_status(gz_ctx *ctx);
 int  gz_table_digest(gz_ctx *ctx, uint8_t out[32]);

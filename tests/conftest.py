@@ -14,6 +14,16 @@ DATA = os.path.join(ROOT, "genz-tokenize_amd", "genz_tokenize", "data")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The table cache lives in a directory of this test session unless the caller chose one: tables are then always BUILT by
+    # the library under test at least once per session (never read from a user cache another build left behind), and only the
+    # dedicated cache test looks at hits.  Child processes of the tests inherit the variable.
+    if "GZ_TABLE_CACHE" not in os.environ:
+        import atexit
+        import shutil
+        import tempfile
+        d = tempfile.mkdtemp(prefix="gz_table_cache_")
+        os.environ["GZ_TABLE_CACHE"] = d
+        atexit.register(shutil.rmtree, d, True)
 
 
 def read_jsonl(name):

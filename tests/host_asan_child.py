@@ -52,7 +52,7 @@ def build(vocab: bytes, bpe: bytes, specials=SPECIALS, read_all=True):
         i = 0
         while L.gz_host_tables_symbol(h, i, C.byref(p), C.byref(ln)) == 0:
             C.string_at(p, ln.value); i += 1
-        for which in range(10):
+        for which in range(1, 10):                              # (0 was the linear-probing pair table of rounds 1-3)
             assert L.gz_host_tables_array(h, which, C.byref(p), C.byref(n)) == 0
             if n.value:
                 C.string_at(p, n.value * WIDTH[which])               # touch every byte of the table

@@ -1,7 +1,7 @@
 """Python model of what the HIP kernels compute FROM THE INTEGER TABLES the host builder emits
 (genz-tokenize_amd/csrc/gz_tables.cpp).  Test infrastructure: it lets the CPU-only suite check the
 table builder and the kernels' closed-form pad / pair formulas against the oracle without a GPU.
-It mirrors gz_kernels.hip step by step (same probe loop, same symbol encoding, same formulas)."""
+It mirrors gz_kernels.hip step by step (same perfect-hash probe, same symbol encoding, same formulas)."""
 import numpy as np
 
 WS = frozenset([0x09, 0x0A, 0x0B, 0x0C, 0x0D, 0x1C, 0x1D, 0x1E, 0x1F, 0x20, 0x85, 0xA0, 0x1680, 0x2028, 0x2029,
@@ -11,10 +11,6 @@ NONE = -1
 M32 = 0xFFFFFFFF
 
 
-def pair_slot(a, b, shift):
-    return ((a * 0x9E3779B1 + b * 0x85EBCA6B) & M32) >> shift
-
-
 def cp_hash(cp):
     h = (cp * 0x9E3779B1) & M32
     return h ^ (h >> 16)
@@ -22,10 +18,6 @@ def cp_hash(cp):
 
 class TableSim:
     def __init__(self, H):
-        pt = H.array(0)                                   # {left, right, merged, rank}
-        self.pair = [tuple(int(x) for x in row) for row in pt]
-        self.mask = len(self.pair) - 1
-        self.shift = 32 - (len(self.pair).bit_length() - 1)
         self.merges = H.array(1)
         self.sym_ids = H.array(2)
         self.bmp = H.array(3)
@@ -69,17 +61,15 @@ class TableSim:
         return None
 
     def probe(self, a, b):
-        if (a | b) & 0xFFF00000:
+        """probe_pair of gz_kernels.hip (displacement from memory, no hot set): the rank, or None.  The merged symbol the
+        kernels take -- the rank, or merges[rank].merged under the alias flag -- must be what the merge list says."""
+        r = self.probe8(a, b, use_hot=False)
+        if r is None:
             return None
-        h = pair_slot(a, b, self.shift)
-        while True:
-            left, right, merged, rank = self.pair[h]
-            if left == a and right == b:
-                assert merged == int(self.merges[rank][2])
-                return rank
-            if left == M32:
-                return None
-            h = (h + 1) & self.mask
+        rank, alias = r
+        merged = int(self.merges[rank][2])
+        assert (merged != rank) == bool(alias)
+        return rank
 
     def initial(self, cp, last):
         s = M32

@@ -274,22 +274,6 @@ def test_csr_host_path_matches_dense(tok, sampler, tmp_path):
     assert np.array_equal(i5, d5["input_ids"]) and np.array_equal(m5, d5["attention_mask"])
 
 
-def test_fused_split_kernel_path():
-    """GZ_SPLIT=1 selects gz_split_kernel (classification + word lookup in ONE pass over the text, word indices from
-    a chained scan with decoupled look-back) instead of classify / scan / words.  It is not the default (measured
-    slower) but it is kept and must stay exact: the golden batches, a reference-digest corpus, the
-    noisy / pair / extreme-shape comparisons run again in a child process with the variable set."""
-    import subprocess
-    import sys
-    env = dict(os.environ, GZ_SPLIT="1")
-    here = os.path.abspath(__file__)
-    r = subprocess.run([sys.executable, "-m", "pytest", here, "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider", "-k",
-                        "g3_random_batched or cfg3_20k or noisy_corpus or noisy_pairs or extreme_batch or long_and_huge or chained"],
-                       env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout and "failed" not in r.stdout
-
-
 def test_big_pipeline_on_small_inputs():
     """Small dense single-text batches run in ONE fused launch (gz_small_kernel); GZ_SMALL=0 sends them through the
     kernel pipeline instead.  The golden vectors and the small-input comparisons of this file run again that way in a
@@ -308,9 +292,8 @@ def test_big_pipeline_on_small_inputs():
 
 
 def test_dense_hash_tables():
-    """The hash tables are built at 1/16 load (a wave's probe loop runs until its last lane is done: long chains cost),
-    so the continue-probing branches of the kernels almost never run on the default build.  GZ_TAB_SLACK=2 builds them at
-    half load, as rounds 1-2 had them: the golden batches, the 20 k-document digests, the noisy corpora (single and
+    """The long-key whole-word table (words of 17..32 bytes, linear probing) is built at 1/16 load, so its continue-probing
+    branches almost never run on the default build.  GZ_TAB_SLACK=2 builds it at half load: the golden batches, the 20 k-document digests, the noisy corpora (single and
     pairs), long words and the small-kernel shapes run again that way in a child process."""
     import subprocess
     import sys
@@ -340,12 +323,12 @@ def test_perfect_hash_overflow_buckets_on_the_gpu():
     assert " passed" in r.stdout and "failed" not in r.stdout
 
 
-@pytest.mark.parametrize("switches", [{"GZ_HOT": "0", "GZ_SIDE": "0", "GZ_BRK_SIDE": "0"}, {"GZ_ASSEMBLE": "2"}, {"GZ_ASSEMBLE": "1"}],
-                         ids=["linear_probing_kernels_one_stream", "lds_row_kernel", "scatter_row_kernel"])
+@pytest.mark.parametrize("switches", [{"GZ_SIDE": "0", "GZ_BRK_SIDE": "0"}, {"GZ_ASSEMBLE": "2"}, {"GZ_ASSEMBLE": "1"}],
+                         ids=["one_stream", "lds_row_kernel", "scatter_row_kernel"])
 def test_alternative_kernels_stay_exact(switches):
-    """Kernels the library keeps beside the default ones: the linear-probing word / merge kernels of rounds 1-2 (GZ_HOT=0; also
-    everything on one stream, GZ_SIDE=0 / GZ_BRK_SIDE=0), and the two older row writers for dense single texts (GZ_ASSEMBLE=2:
-    whole rows through LDS, the pair-mode kernel; 1: the scatter kernel of the ragged layouts).  Each runs the golden batches,
+    """Schedules and kernels the library keeps beside the default ones: everything on one stream (GZ_SIDE=0 / GZ_BRK_SIDE=0), and
+    the pair-mode / ragged row writers run on dense single texts (GZ_ASSEMBLE=2: whole rows through LDS, the pair-mode kernel; 1:
+    the scatter kernel of the ragged layouts).  Each runs the golden batches,
     the 20 k-document digests, the noisy corpora and the long words in a child process, small batches through the pipeline."""
     import subprocess
     import sys
@@ -701,7 +684,8 @@ def test_rccl_gather_two_ranks(tmp_path):
 def test_table_cache_hit_is_identical_and_bad_files_are_refused(tmp_path):
     """gz_load_tables behind the table cache: a second load of the same files is a HIT whose device tables are byte-identical
     to the built ones (gz_table_digest) and which tokenizes like them; a corrupted file, a truncated file and a file of
-    another layout version are refused (rebuilt, rewritten), never trusted; other files get another key."""
+    another layout version are refused (rebuilt, rewritten), and so is a forged file whose key, length and checksum fit but
+    whose content points outside the tables; other files get another key; a shared or impossible cache directory is not used."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -743,8 +727,46 @@ assert damaged(good[:len(good) - 100]) == 3                                     
 assert damaged(good + b"x") == 3                                                 # trailing bytes
 stale = bytearray(good); stale[4] ^= 0x01
 assert damaged(bytes(stale)) == 3                                                # another layout version
+# a FORGED file -- key, length and checksum all fit, but a whole-word entry claims a 31-byte key in a 16-byte slot: every
+# index-bearing field is range-checked on load (the last tabp entry sits before the perfect-hash description and n_words)
+import struct
+M64 = (1 << 64) - 1
+def sum64(p):
+    a, b, n, i = 0x9E3779B97F4A7C15, 0xC2B2AE3D27D4EB4F, len(p), 0
+    while i + 16 <= n:
+        x, y = struct.unpack_from("<QQ", p, i)
+        a = ((a ^ x) * 0xFF51AFD7ED558CCD) & M64; a = ((a << 27) | (a >> 37)) & M64
+        b = ((b ^ y) * 0xC4CEB9FE1A85EC53) & M64; b = ((b << 31) | (b >> 33)) & M64
+        i += 16
+    while i < n:
+        a = ((a ^ p[i]) * 0x100000001B3) & M64; i += 1
+    a ^= (b + n) & M64
+    a ^= a >> 33; a = (a * 0xFF51AFD7ED558CCD) & M64; a ^= a >> 33
+    return a
+HDR = 56                                                                         # magic, layout, key[32], payload_len, payload_sum
+payload = bytearray(good[HDR:])
+assert sum64(bytes(payload)) == struct.unpack_from("<Q", good, 48)[0]             # (this Python restatement of the checksum is right)
+nb = struct.unpack_from("<I", payload, len(payload) - 8 - 28)[0]                  # nbuckets of the word table's perfect hash
+meta_at = len(payload) - 8 - 28 - (8 + 2 * nb) - 32 + 12
+meta = struct.unpack_from("<I", payload, meta_at)[0]
+assert 1 <= (meta & 31) <= 16
+struct.pack_into("<I", payload, meta_at, (meta & ~31) | 31)
+forged = bytearray(good[:HDR]) + payload
+struct.pack_into("<Q", forged, 48, sum64(bytes(payload)))
+assert damaged(bytes(forged)) == 3                                               # consistent, but out of range: refused
 c2, _ = load(unk_token="<unknown>")                                              # other specials: another key, another file
 assert c2._ctx.table_cache_status() == 2 and len(glob.glob(os.path.join(cdir, "*.gztab"))) == 2
+# a directory other users can write to is not used, and a directory that cannot be made is reported (status 4: rebuilt, not written)
+shared = os.path.join(os.path.dirname(cdir), "shared"); os.mkdir(shared); os.chmod(shared, 0o777)
+os.environ["GZ_TABLE_CACHE"] = shared
+d1, _ = load()
+assert d1._ctx.table_cache_status() == 4 and not os.listdir(shared) and d1._ctx.table_digest() == a._ctx.table_digest()
+os.environ["GZ_TABLE_CACHE"] = os.path.join(files[0], "below_a_file")
+d2, _ = load()
+assert d2._ctx.table_cache_status() == 4 and d2._ctx.table_digest() == a._ctx.table_digest()
+os.environ["GZ_TABLE_CACHE"] = os.path.join(os.path.dirname(cdir), "deep", "er", "cache")      # parents are created (0700)
+d3, _ = load()
+assert d3._ctx.table_cache_status() == 2 and (os.stat(os.environ["GZ_TABLE_CACHE"]).st_mode & 0o777) == 0o700
 print("ok build %%.3f s, cached %%.3f s" %% (ta, tb))
 """ % root
     env = dict(os.environ, GZ_TABLE_CACHE=str(tmp_path / "cache"))

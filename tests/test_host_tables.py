@@ -66,9 +66,8 @@ def test_pair_hash_complete(bundled):
     assert sim.probe(syms["n"], syms["n"]) == t.ranks.get(("n", "n"))
 
 
-def test_perfect_hash_pair_table_agrees_with_the_probing_one(bundled):
-    """The merge kernel's table (8-byte entries, hash and displace, hot set) against the linear-probing one, which the
-    test above ties to the oracle's bpe_ranks: every merge is found -- through the hot set and without it -- with its rank,
+def test_perfect_hash_pair_table_is_complete_dense_and_refuses_non_members(bundled):
+    """The pair table (8-byte entries, hash and displace, hot set) against the oracle's bpe_ranks: every merge is found -- through the hot set and without it -- with its rank,
     and the merged symbol IS the rank (symbols are numbered by rank; the bundled file has no two lines that spell the same
     string); pairs that are no merges are refused; the table is dense (load > 0.7) and needs no overflow bucket."""
     import random
