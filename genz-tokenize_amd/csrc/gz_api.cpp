@@ -598,14 +598,14 @@ static int build_word_table(gz_ctx* c, WordImages& W)
     }
     if (found1.empty()) return GZ_OK;            // (the long-key table is only consulted for misses of the first)
     {
-        std::vector<uint32_t> hb(found1.size()), slot_of;
-        for (size_t i = 0; i < found1.size(); ++i) hb[i] = gz_word1_hb(gz_slot1_lo(found1[i]), gz_slot1_hi(found1[i]), found1[i].meta & 31u);
-        auto ha = [](const void* ctx, size_t i, uint32_t k1, uint32_t k2) -> uint32_t {
+        std::vector<uint32_t> slot_of;
+        auto hashes = [](const void* ctx, size_t i, uint32_t k1, uint32_t k2, uint32_t* ha, uint32_t* hb) {
             const GzWordSlot1& e = (*static_cast<const std::vector<GzWordSlot1>*>(ctx))[i];
-            return gz_word1_ha(gz_slot1_lo(e), gz_slot1_hi(e), e.meta & 31u, k1, k2);
+            *hb = gz_word1_hb(gz_slot1_lo(e), gz_slot1_hi(e), e.meta & 31u, k1, k2);
+            *ha = gz_word1_ha_of(*hb);
         };
         GzPhHost& ph = W.ph;
-        gz_ph_build(found1.size(), ha, &found1, hb.data(), ph, slot_of);
+        gz_ph_build(found1.size(), hashes, &found1, ph, slot_of);
         W.tabp.assign(ph.slots, GzWordSlot1{});
         for (size_t i = 0; i < found1.size(); ++i) W.tabp[slot_of[i]] = found1[i];
     }

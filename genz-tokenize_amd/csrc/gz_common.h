@@ -108,18 +108,26 @@ GZ_HD uint32_t gz_word_hash2(const uint64_t k[4], uint32_t len)
 struct GzWordSlot1 { uint32_t k[3]; uint32_t meta; uint32_t k3; uint32_t pad[3]; };
 GZ_HD uint64_t gz_slot1_lo(const GzWordSlot1& e) { return (uint64_t)e.k[0] | ((uint64_t)e.k[1] << 32); }
 GZ_HD uint64_t gz_slot1_hi(const GzWordSlot1& e) { return (uint64_t)e.k[2] | ((uint64_t)e.k3 << 32); }
-// the two hashes of such a key
+// The hashes of such a key, from ONE mix h0 (four multiplies, three xors) with the builder's seeds k1, k2:
+//     bucket: the top bits of ha = finalised h0;   slot: ((h0 ^ displacement) * GZ_PH_MUL) >> sshift   (hb = h0)
+// Two keys with the same h0 would share bucket AND slot under every displacement: the builder then tries other seeds (a
+// 32-bit collision among the few ten thousand words of a vocabulary is rare), and what it cannot place goes to an overflow bucket.
+GZ_HD uint32_t gz_word1_h0(uint32_t a, uint32_t b, uint32_t c, uint32_t d, uint32_t len, uint32_t k1, uint32_t k2)
+{
+    return a * k1 ^ b * k2 ^ c * 0xC2B2AE35u ^ (d + len) * 0x165667B1u;
+}
+GZ_HD uint32_t gz_word1_ha_of(uint32_t h0)
+{
+    h0 ^= h0 >> 15;
+    return h0 * 0x2C1B3C6Du;                                  // (only the top bits are used: the bucket)
+}
+GZ_HD uint32_t gz_word1_hb(uint64_t lo, uint64_t hi, uint32_t len, uint32_t k1, uint32_t k2)
+{
+    return gz_word1_h0((uint32_t)lo, (uint32_t)(lo >> 32), (uint32_t)hi, (uint32_t)(hi >> 32), len, k1, k2);
+}
 GZ_HD uint32_t gz_word1_ha(uint64_t lo, uint64_t hi, uint32_t len, uint32_t k1, uint32_t k2)
 {
-    uint32_t h = (uint32_t)lo * k1 ^ (uint32_t)(lo >> 32) * k2 ^ (uint32_t)hi * 0xC2B2AE35u ^ ((uint32_t)(hi >> 32) + len) * 0x165667B1u;
-    h ^= h >> 15;
-    h *= 0x2C1B3C6Du;
-    return h;                                                 // (only the top bits are used: the bucket, the hot slot)
-}
-GZ_HD uint32_t gz_word1_hb(uint64_t lo, uint64_t hi, uint32_t len)
-{
-    const uint32_t a = (uint32_t)lo, b = (uint32_t)(lo >> 32), c = (uint32_t)hi, d = (uint32_t)(hi >> 32);
-    return a ^ ((b << 11) | (b >> 21)) ^ ((c << 21) | (c >> 11)) ^ ((d << 5) | (d >> 27)) ^ (len << 27);
+    return gz_word1_ha_of(gz_word1_hb(lo, hi, len, k1, k2));
 }
 
 // Device-resident tables, passed to kernels by value.
@@ -146,9 +154,10 @@ struct GzPhHost {
     uint32_t nbuckets = 0, bshift = 0, sshift = 0, slots = 0, k1 = 0, k2 = 0;
     uint32_t n_overflow = 0;                                  // keys placed by linear probing (0 on every table seen so far)
 };
-// ha(key index, k1, k2) and hb[key index]; slot_of[key] receives the key's slot.  Always succeeds.
-void gz_ph_build(size_t n, uint32_t (*ha)(const void* ctx, size_t i, uint32_t k1, uint32_t k2), const void* ctx,
-                 const uint32_t* hb, GzPhHost& out, std::vector<uint32_t>& slot_of);
+// hashes(ctx, key index, k1, k2, &ha, &hb) gives the two hashes of a key under the seeds of an attempt; slot_of[key] receives
+// the key's slot.  Always succeeds.
+void gz_ph_build(size_t n, void (*hashes)(const void* ctx, size_t i, uint32_t k1, uint32_t k2, uint32_t* ha, uint32_t* hb), const void* ctx,
+                 GzPhHost& out, std::vector<uint32_t>& slot_of);
 
 // Host-side result of the loader (tokenize.py:31-57) and of the table build.
 // ---- decoder snapshot (id -> word bytes), tokenize.py:40 -------------------------------------------------------------

@@ -110,7 +110,7 @@ __device__ __forceinline__ bool probe_word16(const GzDeviceTables& T, uint64_t l
     typedef const uint16_t __attribute__((address_space(1)))* g16_t;
     const GzPh& P = T.word0_ph;
     const uint32_t d = ((g16_t)P.disp)[gz_word1_ha(lo, hi, nb, P.k1, P.k2) >> P.bshift];
-    uint32_t h = gz_ph_slot(gz_word1_hb(lo, hi, nb), d, P.sshift);
+    uint32_t h = gz_ph_slot(gz_word1_hb(lo, hi, nb, P.k1, P.k2), d, P.sshift);
     const uint8_t* tab = reinterpret_cast<const uint8_t*>(T.words0p);
     for (;;) {
         const v4u e = *(gw_t)(tab + ((size_t)h << 5));       // key bytes 0..11, len | id << 5

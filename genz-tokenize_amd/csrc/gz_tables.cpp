@@ -6,7 +6,7 @@
 //
 //   symbols   every string bpe() can hold in its `word` tuple: merge operands, merge results, and the
 //             single-character forms the vocab knows (c  and  c+"</w>").  Interned by string identity.
-//   pair_tab  open-addressing hash  (left symbol, right symbol) -> rank, merged symbol   [bpe_ranks.get(pair)]
+//   pair8     perfectly hashed (hash and displace)  (left symbol, right symbol) -> rank = merged symbol   [bpe_ranks.get(pair)]
 //   merges    rank -> (left, right, merged symbol)                              [first + second, tokenize.py:88]
 //   sym_ids   symbol -> vocab id when emitted as a non-final piece (string + "@@") and as the final piece
 //             (string minus "</w>")                                              [encoder.get(tok, unk), :120-121]
@@ -329,13 +329,12 @@ int gz_build_tables(const uint8_t* vocab, size_t vocab_len, const uint8_t* bpe, 
 
     // ---- pair -> rank, perfectly hashed: 8-byte entries, one load per probe ------------------------------------
     {
-        std::vector<uint32_t> hb(pairs.size()), slot_of;
-        for (size_t i = 0; i < pairs.size(); ++i) hb[i] = gz_pair_hb(pairs[i].a, pairs[i].b);
-        auto ha = [](const void* ctx, size_t i, uint32_t k1, uint32_t k2) -> uint32_t {
+        std::vector<uint32_t> slot_of;
+        auto hashes = [](const void* ctx, size_t i, uint32_t k1, uint32_t k2, uint32_t* ha, uint32_t* hb) {
             const Pair& p = (*static_cast<const std::vector<Pair>*>(ctx))[i];
-            return gz_pair_ha(p.a, p.b, k1, k2);
+            *ha = gz_pair_ha(p.a, p.b, k1, k2); *hb = gz_pair_hb(p.a, p.b);
         };
-        gz_ph_build(pairs.size(), ha, &pairs, hb.data(), T.pair_ph, slot_of);
+        gz_ph_build(pairs.size(), hashes, &pairs, T.pair_ph, slot_of);
         T.pair8.assign(T.pair_ph.slots, GzPair8{0xFFFFFFFFu, 0xFFFFFFFFu});
         for (size_t i = 0; i < pairs.size(); ++i) {
             const Pair& p = pairs[i];
@@ -364,8 +363,8 @@ int gz_build_tables(const uint8_t* vocab, size_t vocab_len, const uint8_t* bpe, 
 // more buckets.  Keys of buckets that still cannot be placed (two keys with the same hb in one bucket under every
 // seed: adversarial tables only) are inserted by linear probing and their bucket is marked GZ_PH_OVERFLOW.
 // ---------------------------------------------------------------------------------------------------------------------
-void gz_ph_build(size_t n, uint32_t (*ha)(const void* ctx, size_t i, uint32_t k1, uint32_t k2), const void* ctx,
-                 const uint32_t* hb, GzPhHost& out, std::vector<uint32_t>& slot_of)
+void gz_ph_build(size_t n, void (*hashes)(const void* ctx, size_t i, uint32_t k1, uint32_t k2, uint32_t* ha, uint32_t* hb), const void* ctx,
+                 GzPhHost& out, std::vector<uint32_t>& slot_of)
 {
     size_t slots = 16;
     while (slots * 4 < n * 5) slots <<= 1;                         // load <= 0.8
@@ -384,8 +383,8 @@ void gz_ph_build(size_t n, uint32_t (*ha)(const void* ctx, size_t i, uint32_t k1
         uint32_t bshift = 32;
         while ((size_t(1) << (32 - bshift)) < nb) --bshift;
         const uint32_t k1 = 0x9E3779B1u + 0x3C6EF372u * (uint32_t)attempt, k2 = 0x85EBCA6Bu + 0x1B873592u * (uint32_t)attempt;   // odd
-        std::vector<uint32_t> cnt(nb + 1, 0), bucket_of(n);
-        for (size_t i = 0; i < n; ++i) { bucket_of[i] = ha(ctx, i, k1, k2) >> bshift; ++cnt[bucket_of[i] + 1]; }
+        std::vector<uint32_t> cnt(nb + 1, 0), bucket_of(n), hb(n);
+        for (size_t i = 0; i < n; ++i) { uint32_t ha; hashes(ctx, i, k1, k2, &ha, &hb[i]); bucket_of[i] = ha >> bshift; ++cnt[bucket_of[i] + 1]; }
         for (size_t b = 0; b < nb; ++b) cnt[b + 1] += cnt[b];
         std::vector<uint32_t> keys(n), fill(cnt.begin(), cnt.end() - 1);
         for (size_t i = 0; i < n; ++i) keys[fill[bucket_of[i]]++] = (uint32_t)i;
