@@ -333,15 +333,16 @@ def main():
         if world == 1:                                           # --force-exchange without a launcher: a one-rank group
             for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29531"), ("RANK", "0"), ("WORLD_SIZE", "1")):
                 os.environ.setdefault(k, v)
-        if gloo:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=torch.device("cuda", device))
-    cdev = "cpu" if gloo else "cuda"                             # where the few control scalars of the collectives live
+        # torch.distributed carries the CONTROL plane only -- rendezvous, barriers, the few scalars of the exchange (block sizes,
+        # the elapsed time) -- over gloo on the host.  The DATA plane is the library's own RCCL communicator (gz_comm_init /
+        # gz_gather_rows: grouped ncclSend / ncclRecv over xGMI): RCCL has ONE user per process, and no control scalar
+        # ever waits on a GPU stream.
+        dist.init_process_group("gloo")
+    cdev = "cpu"                                                 # where the control scalars live
 
     import corpus
     from genz_tokenize import Tokenize, _native
-    from genz_tokenize.distributed import rank_shards, global_shard_id, GatherRound
+    from genz_tokenize.distributed import rank_shards, global_shard_id, GatherRound, csr_words
     tok = Tokenize(device=device)
     tok._sync_tables()
     ctx = tok._ctx
@@ -361,14 +362,17 @@ def main():
                       for _ in range(nset)]
         if gather:
             for st in sh["sets"]:
-                st["comp"] = ctx.alloc(4 * sh["n"] * L)            # the shard's rows without padding (worst case: all of it)
+                # this rank's message of the exchange step: [n_real | the rows' real entries] (worst case: every row full)
+                st["block"] = ctx.alloc(4 * (sh["n"] + csr_words(sh["n"] * L, xbits)))
         shards.append(sh)
     m = len(shards)                                               # shards per rank (the same on every rank: 8 / G)
     n = shards[0]["n"]
 
     # root side of the exchange: round j gathers local shard j of every rank (global shard global_shard_id(q, j) comes from
-    # rank q); the bookkeeping -- block sizes, offsets, receive-buffer growth -- is genz_tokenize.distributed.GatherRound
-    rounds = [{"nreal": 0, "comp": 0, "plan": GatherRound(world, xbits)} for _ in range(m)]
+    # rank q); the bookkeeping -- block sizes and offsets -- is genz_tokenize.distributed.GatherRound.  The receive buffers
+    # are sized ONCE, here, for the worst case (every row of every peer full): nothing is allocated, freed or synchronised
+    # for them inside the timed region.
+    rounds = [{"recv": 0, "plan": GatherRound(world, xbits)} for _ in range(m)]
     if gather:
         if not gloo:
             uid = [ctx.comm_unique_id() if rank == 0 else None]
@@ -376,7 +380,8 @@ def main():
             ctx.comm_init(uid[0], rank, world)
         if rank == 0:
             for r in rounds:
-                r["nreal"] = ctx.alloc(4 * n * world)
+                r["plan"].capacity = world * (n + csr_words(n * L, xbits))
+                r["recv"] = ctx.alloc(4 * r["plan"].capacity)
 
     def gloo_gatherv(d_src, my_words, d_dst, words):
         """The gatherv of gz_gather_rows over gloo: this rank's `my_words` int32 words leave the device, travel by
@@ -402,27 +407,24 @@ def main():
             w0 += k
 
     def exchange(j, st):
-        """Exchange step of local shard j: every rank sends the shard's rows WITHOUT the padding (row lengths + the rows'
-        real entries, CSR form) straight to rank 0 over its own xGMI link (grouped ncclSend/ncclRecv)."""
+        """Exchange step of local shard j: every rank sends the shard's rows WITHOUT the padding -- ONE block [row lengths | the
+        rows' real entries] -- straight to rank 0 over its own xGMI link (one grouped ncclSend / ncclRecv per shard).  The host
+        waits for the compact kernel of THIS shard only (the next shard's kernels are already queued on the main stream), then
+        the ranks tell each other their block sizes over gloo."""
         r = rounds[j]
         plan = r["plan"]
-        total = ctx.compact_rows(st["ids"], st["nreal"], n, L, st["comp"], bits=xbits)
-        t = torch.tensor([total], dtype=torch.int64, device=cdev)
-        lst = [torch.zeros_like(t) for _ in range(world)]
-        dist.all_gather(lst, t)
-        cap = plan.announce([int(x.item()) for x in lst])
-        if rank == 0 and cap != plan.capacity:                    # the receive buffer grows (first round, or a fuller shard)
-            ctx.sync()
-            if r["comp"]:
-                ctx.free(r["comp"])
-            r["comp"] = ctx.alloc(4 * cap)
-            plan.capacity = cap
+        total = ctx.compact_block(st["ids"], st["nreal"], n, L, st["block"], bits=xbits)
+        lst = [None] * world
+        dist.all_gather_object(lst, int(total))
+        plan.announce(lst)                                        # entries per rank -> words per rank (n_real header not included)
+        words = [n + w for w in plan.words]                      # a block = n row lengths + the entries
+        if sum(words) > plan.capacity:
+            sys.exit("bench: receive buffer too small (cannot happen: it holds the worst case)")
         if gloo:
-            gloo_gatherv(st["nreal"], n, r["nreal"] if rank == 0 else 0, [n] * world)
-            gloo_gatherv(st["comp"], plan.words[rank], r["comp"], plan.words)
+            gloo_gatherv(st["block"], words[rank], r["recv"], words)
         else:
-            ctx.gather_rows(st["nreal"], n, 1, r["nreal"] if rank == 0 else 0, [n] * world, 0)
-            ctx.gather_rows(st["comp"], plan.words[rank], 1, r["comp"], plan.words, 0)
+            ctx.gather_rows(st["block"], words[rank], 1, r["recv"] if rank == 0 else 0, words, 0)
+        r["words"] = words
 
     kernel_ms = []
     step_no = [0]
@@ -503,7 +505,7 @@ def main():
             plan = r["plan"]
             for q in range(world):
                 gid = global_shard_id(q, j, world, N_SHARDS)
-                ctx.expand_rows(r["comp"] + 4 * plan.word_offset(q), r["nreal"] + 4 * n * q, n, L, d_ci, d_cm, bits=xbits)
+                ctx.expand_block(r["recv"] + 4 * sum(r["words"][:q]), n, L, d_ci, d_cm, bits=xbits)
                 ctx.sync()
                 blk = np.empty((n, L), dtype=np.int32); ctx.d2h(blk, d_ci)
                 mblk = np.empty((n, L), dtype=np.int32); ctx.d2h(mblk, d_cm)
@@ -562,7 +564,7 @@ def main():
         in_b = shards[0]["in_bytes"] if m == 1 else float(np.mean([sh["in_bytes"] for sh in shards]))
         algo = _algo_bytes(in_b, n, L)
         achieved = algo / (k_ms * 1e-3) / 1e9
-        shard_traffic = _pmc_traffic("r03_pmc_traffic_shard.json")
+        shard_traffic = _pmc_traffic("r04_pmc_traffic_shard.json")
         out = {
             "metric": "UTF-8 MB/s tokenized (Tokenize.__call__ hot path: split + BPE + vocab lookup + pad/trunc + mask)",
             "value": round(total_bytes * args.steps / elapsed / 1e6, 2),
@@ -597,16 +599,19 @@ def main():
                          # the text is streamed twice with 16-byte-per-lane loads (classify, words), which FETCH_SIZE counts at half
                          # their bytes on gfx950 (MI355X_MICROARCH.md, HBM): the corrected figure adds the uncounted half of both passes
                          "traffic_corrected": int(shard_traffic["bytes_per_step"] + in_b) if shard_traffic else None,
-                         "traffic_note": ("profiles/r03_pmc_traffic_shard.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over one "
+                         "traffic_note": ("profiles/r04_pmc_traffic_shard.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over one "
                                           "launch on shard 0 (1.25 M documents), same kernel sources (sha %s); reads of 16-B streams are "
                                           "half-counted on gfx950, not corrected" % kernel_source_sha16()) if shard_traffic else
-                                         "null: profiles/r03_pmc_traffic_shard.json is absent or was taken on other kernel sources",
+                                         "null: profiles/r04_pmc_traffic_shard.json is absent or was taken on other kernel sources",
                          "algorithmic_bytes_per_launch": int(algo),
                          "kernel_ms_avg": round(k_ms, 4), "launches_timed": len(kernel_ms),
                          "timed_with": "hipEvents on the library's stream around each launch of the pipeline, inside the timed region"},
             "verified": verify, "verified_items": checked if len(checked) <= 24 else checked[:24] + ["..."],
         }
         out.update(sec)
+        if "headline_host_paths" in sec:
+            # timing (ii) of SURVEY.md 8(d) for the SAME job, first-class: pinned host text in, pinned CSR rows out (PCIe-bound)
+            out["value_host_e2e_MB_per_s"] = sec["headline_host_paths"].get("MB_per_s")
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
@@ -675,7 +680,7 @@ def secondary(ctx, tok, flags, args, cfg2):
     n_tok = int(mask.sum(dtype=np.int64))
     del ids, mask
     algo = _algo_bytes(R.in_bytes, R.n, L)
-    traffic = _pmc_traffic("r03_pmc_traffic.json")
+    traffic = _pmc_traffic("r04_pmc_traffic.json")
     # (ii) device end-to-end: host buffers in, host buffers out (PCIe both ways).  The library's host path for batches is
     # gz_encode_batch_csr: sub-batches, text H2D / kernels / D2H on three streams, and only the rows' real entries
     # (16-bit) + 4 bytes per document come back; the buffers are pinned (gz_host_alloc), as SURVEY.md 8(d) (ii) says.
@@ -721,9 +726,9 @@ def secondary(ctx, tok, flags, args, cfg2):
                      "frac": round(algo / k_ms / 1e6 / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_launch": int(algo),
                      "kernel_ms_avg": round(k_ms, 4),
                      "traffic": traffic["bytes_per_step"] if traffic else None,
-                     "traffic_source": "profiles/r03_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, summed over the "
+                     "traffic_source": "profiles/r04_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, summed over the "
                                        "launch's kernels; reads not corrected for the gfx950 half-count)" if traffic else
-                                       "none for this build (profiles/r03_pmc_traffic.json absent or taken on other kernel sources)"}}
+                                       "none for this build (profiles/r04_pmc_traffic.json absent or taken on other kernel sources)"}}
     # ---- the same step with the whole-word tables off: every word through the merge loop
     k2 = R.kernel_ms(flags | _native.GZ_NO_WORD_TABLE, reps=3)
     out["merge_loop_only"] = {"kernel_ms_avg": round(k2, 4), "MB_per_s_kernel": round(R.in_bytes / k2 / 1e3, 1)}
@@ -821,12 +826,16 @@ def secondary(ctx, tok, flags, args, cfg2):
             sys.exit("bench: " + e5)
         v5 = "C-oracle sha256 over all %d documents (tests/golden/g5_hashes.json cfg5_50k; its first 300 documents also hashed by the reference): match" % R5.n
     a5 = _algo_bytes(R5.in_bytes, R5.n, L5)
+    t5j = _pmc_traffic("r04_pmc_traffic_cfg4.json")
     out["configs_4_long_docs"] = {
         "workload": "BASELINE configs[4]: Tokenize.fromFile custom tables (100 000-entry vocab, %d merges without the #version header), "
                     "%d documents of <= 4 000 characters (%.1f MB), max_len=%d pad+trunc" % (tok5._ctx.table_info()[2], R5.n, R5.in_bytes / 1e6, L5),
         "kernel_ms_avg": round(k5, 4), "MB_per_s_kernel": round(R5.in_bytes / k5 / 1e3, 1), "verified": v5,
         "roofline": {"bound": "hbm", "achieved": round(a5 / k5 / 1e6, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": round(a5 / k5 / 1e6 / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_launch": int(a5), "traffic": None}}
+                     "frac": round(a5 / k5 / 1e6 / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_launch": int(a5),
+                     "traffic": t5j["bytes_per_step"] if t5j else None,
+                     "traffic_source": "profiles/r04_pmc_traffic_cfg4.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/prof_cfg5.py)"
+                                       if t5j else "none for this build (profiles/r04_pmc_traffic_cfg4.json absent or taken on other kernel sources)"}}
     R5.free()
     return out
 

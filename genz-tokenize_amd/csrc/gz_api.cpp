@@ -1737,6 +1737,27 @@ int gz_expand_rows16(gz_ctx* c, const uint16_t* compact_dev, const int32_t* n_re
     return expand_impl(c, compact_dev, 16, n_real_dev, n_rows, row_len, ids_dev, mask_dev);
 }
 
+int gz_compact_block(gz_ctx* c, const int32_t* rows_dev, const int32_t* n_real_dev, int64_t n_rows, int32_t row_len, int32_t bits,
+                     int32_t* block_dev, int64_t* total_host)
+{
+    if (!c || !block_dev || !n_real_dev || n_rows < 0 || (bits != 16 && bits != 32)) return c ? fail(c, GZ_E_INVALID, "bad arguments") : GZ_E_INVALID;
+    {
+        // the row lengths in front of the entries (on the exchange stream, behind the encode call they belong to)
+        std::lock_guard<std::mutex> lk(c->mu);
+        HIPCHK(c, hipSetDevice(c->device));
+        int rc;
+        if ((rc = x_begin(c))) return rc;
+        if (n_rows) HIPCHK(c, hipMemcpyAsync(block_dev, n_real_dev, (size_t)n_rows * 4, hipMemcpyDeviceToDevice, c->xstream));
+        if ((rc = x_end(c))) return rc;
+    }
+    return compact_impl(c, rows_dev, n_real_dev, n_rows, row_len, block_dev + n_rows, bits, total_host);
+}
+int gz_expand_block(gz_ctx* c, const int32_t* block_dev, int32_t bits, int64_t n_rows, int32_t row_len, int32_t* ids_dev, int32_t* mask_dev)
+{
+    if (!c || !block_dev || n_rows < 0 || (bits != 16 && bits != 32)) return c ? fail(c, GZ_E_INVALID, "bad arguments") : GZ_E_INVALID;
+    return expand_impl(c, block_dev + n_rows, bits, block_dev, n_rows, row_len, ids_dev, mask_dev);
+}
+
 // ---- multi-GPU exchange step --------------------------------------------------------------------------------------
 int gz_comm_unique_id(uint8_t id_out[128])
 {

@@ -27,7 +27,7 @@ SYMBOLS = [
     "gz_vocab_entry", "gz_merge_entry", "gz_encode_batch", "gz_encode_batch_csr", "gz_host_alloc", "gz_host_free", "gz_encode_batch_device", "gz_encode_batch_device_h", "gz_sync",
     "gz_word_token_counts", "gz_bpe_word", "gz_symbol_utf8", "gz_device_alloc", "gz_device_free", "gz_memcpy_h2d", "gz_memcpy_d2h",
     "gz_timing", "gz_timing_history", "gz_decoder_snapshot", "gz_decode_batch", "gz_decode_batch_device", "gz_preprocess_batch",
-    "gz_preprocess_batch_device", "gz_block_create", "gz_block_release", "gz_block_dlpack", "gz_dlpack_capsule_destructor", "gz_exchange_select", "gz_comm_unique_id", "gz_comm_init", "gz_gather_rows", "gz_compact_rows", "gz_expand_rows", "gz_compact_rows16", "gz_expand_rows16",
+    "gz_preprocess_batch_device", "gz_block_create", "gz_block_release", "gz_block_dlpack", "gz_dlpack_capsule_destructor", "gz_exchange_select", "gz_comm_unique_id", "gz_comm_init", "gz_gather_rows", "gz_compact_rows", "gz_expand_rows", "gz_compact_rows16", "gz_expand_rows16", "gz_compact_block", "gz_expand_block",
     "gz_host_tables_create", "gz_host_tables_destroy", "gz_host_tables_array", "gz_host_tables_vocab_entry",
     "gz_host_tables_merge_entry", "gz_host_tables_symbol",
 ]
@@ -432,6 +432,17 @@ class Context:
     def expand_rows(self, d_compact, d_n_real, n_rows, row_len, d_ids, d_mask, bits: int = 32):
         fn = self.lib.gz_expand_rows16 if bits == 16 else self.lib.gz_expand_rows
         self._check(fn(self.handle, C.c_void_p(d_compact), C.c_void_p(d_n_real), n_rows, row_len, C.c_void_p(d_ids), C.c_void_p(d_mask)))
+
+    def compact_block(self, d_rows, d_n_real, n_rows, row_len, d_block, bits: int = 16) -> int:
+        """One rank's message of the exchange step: [int32 n_real[n_rows] | the rows' real entries, `bits` bits each] into
+        d_block; returns the number of entries."""
+        total = C.c_int64()
+        self._check(self.lib.gz_compact_block(self.handle, C.c_void_p(d_rows), C.c_void_p(d_n_real), n_rows, row_len, bits,
+                                              C.c_void_p(d_block), C.byref(total)))
+        return total.value
+
+    def expand_block(self, d_block, n_rows, row_len, d_ids, d_mask, bits: int = 16):
+        self._check(self.lib.gz_expand_block(self.handle, C.c_void_p(d_block), bits, n_rows, row_len, C.c_void_p(d_ids), C.c_void_p(d_mask)))
 
     def gather_rows(self, d_send, n_rows_local, row_len, d_recv, rows_per_rank, root=0):
         rpr = np.ascontiguousarray(rows_per_rank, dtype=np.int64)

@@ -297,6 +297,14 @@ int  gz_compact_rows16(gz_ctx *ctx, const int32_t *rows_dev, const int32_t *n_re
                        uint16_t *out_dev, int64_t *total_host);
 int  gz_expand_rows16(gz_ctx *ctx, const uint16_t *compact_dev, const int32_t *n_real_dev, int64_t n_rows, int32_t row_len,
                       int32_t *ids_dev, int32_t *mask_dev);
+/* One rank's whole message of the exchange step as ONE block (one ncclSend per peer and shard):
+ *     block_dev = [ int32 n_real[n_rows] | the rows' real entries back to back, `bits` (16 | 32) bits each ]
+ * gz_compact_block writes it (total_host receives the number of entries; the block is n_rows + ceil(total * bits / 32)
+ * int32 words long), gz_expand_block is the inverse on the receiving side. */
+int  gz_compact_block(gz_ctx *ctx, const int32_t *rows_dev, const int32_t *n_real_dev, int64_t n_rows, int32_t row_len,
+                      int32_t bits, int32_t *block_dev, int64_t *total_host);
+int  gz_expand_block(gz_ctx *ctx, const int32_t *block_dev, int32_t bits, int64_t n_rows, int32_t row_len,
+                     int32_t *ids_dev, int32_t *mask_dev);
 
 #ifdef __cplusplus
 }

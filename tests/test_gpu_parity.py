@@ -895,8 +895,8 @@ print("ok")
 
 @pytest.mark.parametrize("world", [2, 4])
 def test_bench_multirank_exchange_on_one_gpu_over_gloo(world):
-    """The N > 1 code of bench.py -- shard ownership, compact_rows16, exchange_select, per-round totals / block offsets,
-    receive-buffer growth, per-peer expand + verification at the root -- executed end to end with `world` ranks on ONE GPU:
+    """The N > 1 code of bench.py -- shard ownership, gz_compact_block, exchange_select, per-round block sizes / offsets over the
+    gloo control group, per-peer expand + verification at the root -- executed end to end with `world` ranks on ONE GPU:
     the transport is gloo (D2H -> send/recv -> H2D) because RCCL refuses two ranks on one device; everything else is the
     product's.  bench.py exits non-zero when any rank's shard or any gathered block differs from the C oracle."""
     import json
@@ -917,6 +917,55 @@ def test_bench_multirank_exchange_on_one_gpu_over_gloo(world):
     assert "gloo" in out["config"]["sharding"]
     assert len([c for c in out["verified_items"] if c.startswith("gathered shard")]) == 8     # every shard arrived and was checked
     assert out["value"] > 0
+
+
+def test_bench_exchange_step_over_rccl_with_one_rank():
+    """`bench.py --force-exchange` under torch.distributed.run with ONE rank and the product transport: the library's own RCCL
+    communicator (ncclCommInitRank, gz_gather_rows on the exchange stream, double-buffered gz_exchange_select) beside the gloo
+    control group, exactly the code path of N > 1 -- all this box can run of it (RCCL refuses two ranks on one device).  Every
+    gathered block is expanded and verified against the C oracle; bench.py exits non-zero on any difference."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
+           "--docs", "160000", "--force-exchange", "--no-secondary"]
+    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=420)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert out["n_gpus"] == 1 and "RCCL gatherv" in out["config"]["sharding"]
+    assert len([c for c in out["verified_items"] if c.startswith("gathered shard")]) == 8
+    assert out["value"] > 0
+
+
+def test_compact_block_round_trip(tok):
+    """gz_compact_block / gz_expand_block (one rank's message of the exchange step: [row lengths | real entries]) against the
+    dense rows they came from, 16- and 32-bit entries."""
+    import corpus
+    ctx = tok._ctx
+    text, offs, _ = corpus.config_corpus(3, n_docs=3000, seed=77)
+    L = 64
+    r = tok.encode_packed(text, offs, max_len=L)
+    ids, nr = np.ascontiguousarray(r["input_ids"]), np.ascontiguousarray(r["n_real"] if "n_real" in r else r["attention_mask"].sum(axis=1).astype(np.int32))
+    n = ids.shape[0]
+    d_ids, d_nr = ctx.alloc(ids.nbytes), ctx.alloc(4 * n)
+    ctx.h2d(d_ids, ids); ctx.h2d(d_nr, nr.astype(np.int32))
+    for bits in (16, 32):
+        d_blk = ctx.alloc(4 * (n + n * L)); d_i2, d_m2 = ctx.alloc(ids.nbytes), ctx.alloc(ids.nbytes)
+        total = ctx.compact_block(d_ids, d_nr, n, L, d_blk, bits=bits)
+        assert total == int(nr.sum())
+        head = np.empty(n, dtype=np.int32); ctx.sync(); ctx.d2h(head, d_blk)
+        assert np.array_equal(head, nr)
+        ctx.expand_block(d_blk, n, L, d_i2, d_m2, bits=bits); ctx.sync()
+        i2 = np.empty_like(ids); m2 = np.empty_like(ids); ctx.d2h(i2, d_i2); ctx.d2h(m2, d_m2)
+        assert np.array_equal(i2, ids) and np.array_equal(m2, r["attention_mask"])
+        for q in (d_blk, d_i2, d_m2):
+            ctx.free(q)
+    ctx.free(d_ids); ctx.free(d_nr)
 
 
 def test_gather_rows_refuses_bad_arguments_before_opening_a_group(tok):
