@@ -191,7 +191,6 @@ struct GzHostTables {
     std::vector<GzPair8>     pair8;      // pair -> rank, perfectly hashed
     GzPhHost                 pair_ph;
     std::vector<GzPair8>     pair_hot;   // direct-mapped hot set (GZ_PAIR_HOT_SLOTS entries)
-    std::vector<uint64_t>    enc_hint;   // per encoder entry: the count the vocab line carries (0: none) -- a speed hint only
 };
 
 // Returns GZ_OK / GZ_E_UTF8 / GZ_E_LIMIT; `err` receives a message.

@@ -120,11 +120,13 @@ struct OrderedDict {            // a Python dict[str, int]: insertion order, ove
     std::unordered_map<std::string, size_t> pos;
     std::vector<std::string> keys;
     std::vector<int32_t> vals;
-    void set(const std::string& k, int32_t v)
+    std::vector<uint64_t> aux;  // a second value per key that is NOT part of the dict (a hint / a field count): the last set() wins
+    void reserve(size_t n) { pos.reserve(n); keys.reserve(n); vals.reserve(n); aux.reserve(n); }
+    void set(const std::string& k, int32_t v, uint64_t a = 0)
     {
         auto it = pos.find(k);
-        if (it == pos.end()) { pos.emplace(k, keys.size()); keys.push_back(k); vals.push_back(v); }
-        else vals[it->second] = v;
+        if (it == pos.end()) { pos.emplace(k, keys.size()); keys.push_back(k); vals.push_back(v); aux.push_back(a); }
+        else { vals[it->second] = v; aux[it->second] = a; }
     }
     const int32_t* get(const std::string& k) const
     {
@@ -156,7 +158,11 @@ int gz_build_tables(const uint8_t* vocab, size_t vocab_len, const uint8_t* bpe, 
 
     // ---- encoder (tokenize.py:31-37, :44-51) ------------------------------------------------------------
     OrderedDict enc;
-    std::unordered_map<std::string, uint64_t> hint;
+    {
+        size_t lines = 8;
+        for (char32_t c : vtext) lines += c == '\n';
+        enc.reserve(lines);
+    }
     for (int i = 0; i < 5; ++i) enc.set(specials[i], i);
     {
         size_t i = 0, n = vtext.size();
@@ -173,31 +179,17 @@ int gz_build_tables(const uint8_t* vocab, size_t vocab_len, const uint8_t* bpe, 
             if (k > a) cut = k - 1;                       // position of the last ' '
             else cut = (b > a) ? b - 1 : a;               // no space: line[:-1]; empty line: ''
             std::string word = to_utf8(vtext.data() + a, vtext.data() + cut);
-            enc.set(word, (int32_t)enc.size());           // len(encoder) BEFORE the insertion
-            {
-                // what follows the last space is ignored by the reference; when it is a number (the bundled vocab: the
-                // word's corpus count) it is kept as a HINT for which words go into the kernels' LDS hot set
-                uint64_t cnt = 0;
-                bool digits = k > a && cut + 1 < b;
-                for (size_t q = cut + 1; q < b && digits; ++q) {
-                    if (vtext[q] < '0' || vtext[q] > '9' || cnt > (1ull << 56)) digits = false;
-                    else cnt = cnt * 10 + (uint64_t)(vtext[q] - '0');
-                }
-                hint[word] = digits ? cnt : 0;
-            }
+            enc.set(word, (int32_t)enc.size());           // len(encoder) BEFORE the insertion (what follows the last space is ignored)
             i = (j < n) ? j + 1 : j;
         }
     }
     T.enc_words = enc.keys;
     T.enc_ids = enc.vals;
-    T.enc_hint.assign(enc.keys.size(), 0);
-    for (size_t i = 0; i < enc.keys.size(); ++i) { auto it = hint.find(enc.keys[i]); if (it != hint.end()) T.enc_hint[i] = it->second; }
     for (int i = 0; i < 5; ++i) T.special_ids[i] = *enc.get(specials[i]);
     const int32_t unk_id = T.special_ids[4];
 
     // ---- bpe_ranks (tokenize.py:53-57) --------------------------------------------------------------------
-    OrderedDict ranks;                                    // key = fields joined by '\n'
-    std::unordered_map<std::string, int32_t> nfields;
+    OrderedDict ranks;                                    // key = fields joined by '\n'; aux = the number of fields
     {
         // read().split('\n')[:-1]
         std::vector<std::pair<size_t, size_t>> rows;
@@ -211,6 +203,7 @@ int gz_build_tables(const uint8_t* vocab, size_t vocab_len, const uint8_t* bpe, 
         }
         rows.pop_back();
         if (rows.size() > GZ_MAX_RANKS) { err = "bpe file: too many lines"; return GZ_E_LIMIT; }
+        ranks.reserve(rows.size());
         for (size_t r = 0; r < rows.size(); ++r) {
             std::string key;
             int32_t nf = 0;
@@ -225,13 +218,12 @@ int gz_build_tables(const uint8_t* vocab, size_t vocab_len, const uint8_t* bpe, 
                 ++nf;
                 p = q;
             }
-            ranks.set(key, (int32_t)r);
-            nfields[key] = nf;
+            ranks.set(key, (int32_t)r, (uint64_t)nf);
         }
-        T.rank_keys = ranks.keys;
-        T.rank_vals = ranks.vals;
         T.rank_nfields.resize(ranks.size());
-        for (size_t k = 0; k < ranks.size(); ++k) T.rank_nfields[k] = nfields[ranks.keys[k]];
+        for (size_t k = 0; k < ranks.size(); ++k) T.rank_nfields[k] = (int32_t)ranks.aux[k];
+        T.rank_keys = std::move(ranks.keys);              // (the dict is complete: its insertion-ordered halves move out)
+        T.rank_vals = std::move(ranks.vals);
         T.merges.assign(rows.size(), GzMergeInfo{0, 0, 0, 0});
     }
 
@@ -242,16 +234,20 @@ int gz_build_tables(const uint8_t* vocab, size_t vocab_len, const uint8_t* bpe, 
     // are no merges stay unused ids (empty strings).
     std::unordered_map<std::string, uint32_t> sym_of;
     const size_t n_lines = T.merges.size();
+    sym_of.reserve(2 * n_lines + 1024);
     struct Pair { uint32_t a, b, rank; };
     std::vector<Pair> pairs;
-    struct Fields { std::string a, b; uint32_t rank; };
+    struct Fields { std::string a, b, m; uint32_t rank; };       // first, second, first + second (tokenize.py:88)
     std::vector<Fields> two;
-    for (size_t k = 0; k < ranks.size(); ++k) {
+    two.reserve(T.rank_keys.size());
+    for (size_t k = 0; k < T.rank_keys.size(); ++k) {
         if (T.rank_nfields[k] != 2) continue;             // such a key can never equal a (first, second) pair
-        const std::string& key = ranks.keys[k];
+        const std::string& key = T.rank_keys[k];
         size_t nl = key.find('\n');
-        two.push_back(Fields{key.substr(0, nl), key.substr(nl + 1), (uint32_t)ranks.vals[k]});
-        const std::string m = two.back().a + two.back().b;
+        two.push_back(Fields{key.substr(0, nl), key.substr(nl + 1), std::string(), (uint32_t)T.rank_vals[k]});
+        two.back().m.reserve(key.size());
+        two.back().m.append(two.back().a).append(two.back().b);
+        const std::string& m = two.back().m;
         auto it = sym_of.find(m);
         if (it == sym_of.end()) sym_of.emplace(m, two.back().rank);
         else if (two.back().rank < it->second) it->second = two.back().rank;
@@ -267,7 +263,7 @@ int gz_build_tables(const uint8_t* vocab, size_t vocab_len, const uint8_t* bpe, 
         return id;
     };
     for (const Fields& f : two) {
-        uint32_t ia = intern(f.a), ib = intern(f.b), im = intern(f.a + f.b);
+        uint32_t ia = intern(f.a), ib = intern(f.b), im = intern(f.m);
         T.merges[f.rank] = GzMergeInfo{ia, ib, im, 0};
         pairs.push_back({ia, ib, f.rank});
     }
@@ -285,12 +281,15 @@ int gz_build_tables(const uint8_t* vocab, size_t vocab_len, const uint8_t* bpe, 
 
     // ---- symbol -> vocab ids ----------------------------------------------------------------------------------
     T.sym_ids.resize(T.symbols.size());
+    std::string probe;
     for (size_t s = 0; s < T.symbols.size(); ++s) {
         const std::string& str = T.symbols[s];
-        const int32_t* nf = enc.get(str + "@@");
+        probe.assign(str).append("@@");
+        const int32_t* nf = enc.get(probe);
         int32_t fin = unk_id;
         if (ends_with(str, "</w>")) {
-            const int32_t* f = enc.get(str.substr(0, str.size() - 4));
+            probe.assign(str, 0, str.size() - 4);
+            const int32_t* f = enc.get(probe);
             if (f) fin = *f;
         }
         T.sym_ids[s] = GzSymIds{nf ? *nf : unk_id, fin};

@@ -104,6 +104,8 @@ def load_library():
     L.gz_host_tables_merge_entry.argtypes = [vp, i64, P(vp), P(i32), P(i32), P(i32)]
     L.gz_host_tables_symbol.argtypes = [vp, i32, P(vp), P(i32)]
     for name in SYMBOLS:
+        if os.environ.get("GZ_LIBRARY") and not hasattr(L, name):
+            continue                                     # (an older build loaded for an A/B run: entry points it lacks stay unbound)
         fn = getattr(L, name)
         if name not in ("gz_destroy", "gz_last_error", "gz_bpe_word", "gz_host_tables_destroy", "gz_block_release", "gz_block_dlpack",
                         "gz_dlpack_capsule_destructor"):
