@@ -604,8 +604,30 @@ static int build_word_table(gz_ctx* c, WordImages& W)
             *hb = gz_word1_hb(gz_slot1_lo(e), gz_slot1_hi(e), e.meta & 31u, k1, k2);
             *ha = gz_word1_ha_of(*hb);
         };
+        // the words running text consists of (by the counts the vocab file carries; without counts: the file's order) share the
+        // table's first lines: a hint to the builder, see gz_ph_build
+        const uint32_t hot_slots = gz_word_hot_slots();
+        std::vector<uint8_t> hotf;
+        if (hot_slots) {
+            std::unordered_map<std::string, uint64_t> weight;
+            bool any = false;
+            for (uint64_t h : H.enc_count) if (h) { any = true; break; }
+            weight.reserve(H.enc_words.size());
+            for (size_t i = 0; i < H.enc_words.size(); ++i) weight[H.enc_words[i]] = any ? H.enc_count[i] : (uint64_t)(H.enc_words.size() - i);
+            std::vector<std::pair<uint64_t, uint32_t>> order(found1.size());
+            for (size_t i = 0; i < found1.size(); ++i) {
+                char key[16];
+                std::memcpy(key, found1[i].k, 12); std::memcpy(key + 12, &found1[i].k3, 4);
+                auto it = weight.find(std::string(key, found1[i].meta & 31u));
+                order[i] = {it == weight.end() ? 0 : it->second, (uint32_t)i};
+            }
+            std::sort(order.begin(), order.end(), [](const std::pair<uint64_t, uint32_t>& x, const std::pair<uint64_t, uint32_t>& y) { return x.first != y.first ? x.first > y.first : x.second < y.second; });
+            hotf.assign(found1.size(), 0);
+            const size_t nhot = std::min<size_t>(found1.size(), (size_t)hot_slots * 7 / 8);     // (an eighth of the region stays free: the last ones still find a slot)
+            for (size_t i = 0; i < nhot; ++i) hotf[order[i].second] = 1;
+        }
         GzPhHost& ph = W.ph;
-        gz_ph_build(found1.size(), hashes, &found1, ph, slot_of);
+        gz_ph_build(found1.size(), hashes, &found1, ph, slot_of, hotf.empty() ? nullptr : hotf.data(), hot_slots);
         W.tabp.assign(ph.slots, GzWordSlot1{});
         for (size_t i = 0; i < found1.size(); ++i) W.tabp[slot_of[i]] = found1[i];
     }

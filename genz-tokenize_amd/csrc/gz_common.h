@@ -130,6 +130,18 @@ GZ_HD uint32_t gz_word1_ha(uint64_t lo, uint64_t hi, uint32_t len, uint32_t k1, 
     return gz_word1_ha_of(gz_word1_hb(lo, hi, len, k1, k2));
 }
 
+// slots at the head of the whole-word table that the builder reserves for the most frequent words (GZ_PH_HOT_SLOTS = 0 .. 8192
+// overrides it when the tables are built; 0: no steering)
+inline uint32_t gz_word_hot_slots()
+{
+    static const uint32_t v = [] {
+        const char* e = getenv("GZ_PH_HOT_SLOTS");
+        const long k = e ? atol(e) : -1;
+        return (uint32_t)(k >= 0 && k <= 8192 ? k : 1024);
+    }();
+    return v;
+}
+
 // Device-resident tables, passed to kernels by value.
 struct GzDeviceTables {
     const GzMergeInfo* merges;      uint32_t n_ranks;
@@ -156,8 +168,13 @@ struct GzPhHost {
 };
 // hashes(ctx, key index, k1, k2, &ha, &hb) gives the two hashes of a key under the seeds of an attempt; slot_of[key] receives
 // the key's slot.  Always succeeds.
+// hot (optional, [n]): 1 = a key that is looked up very often.  Such keys are steered into the first `hot_slots` slots of the
+// table -- the builder is free to choose any displacement that works, so it prefers one that lands a bucket's hot key there
+// and keeps every other key out -- and so share a few cache lines that stay resident in every CU's L1 (a perfect hash
+// otherwise puts the few thousand words running text consists of on as many different lines).  Placement only: what a probe
+// returns never depends on it.
 void gz_ph_build(size_t n, void (*hashes)(const void* ctx, size_t i, uint32_t k1, uint32_t k2, uint32_t* ha, uint32_t* hb), const void* ctx,
-                 GzPhHost& out, std::vector<uint32_t>& slot_of);
+                 GzPhHost& out, std::vector<uint32_t>& slot_of, const uint8_t* hot = nullptr, uint32_t hot_slots = 0);
 
 // Host-side result of the loader (tokenize.py:31-57) and of the table build.
 // ---- decoder snapshot (id -> word bytes), tokenize.py:40 -------------------------------------------------------------
@@ -191,6 +208,8 @@ struct GzHostTables {
     std::vector<GzPair8>     pair8;      // pair -> rank, perfectly hashed
     GzPhHost                 pair_ph;
     std::vector<GzPair8>     pair_hot;   // direct-mapped hot set (GZ_PAIR_HOT_SLOTS entries)
+    std::vector<uint64_t>    enc_count;  // per encoder entry: the count the vocab line carries (0: none) -- only ever a PLACEMENT hint:
+                                         // the most frequent words share the first lines of the whole-word table (gz_ph_build)
 };
 
 // Returns GZ_OK / GZ_E_UTF8 / GZ_E_LIMIT; `err` receives a message.

@@ -179,12 +179,21 @@ int gz_build_tables(const uint8_t* vocab, size_t vocab_len, const uint8_t* bpe, 
             if (k > a) cut = k - 1;                       // position of the last ' '
             else cut = (b > a) ? b - 1 : a;               // no space: line[:-1]; empty line: ''
             std::string word = to_utf8(vtext.data() + a, vtext.data() + cut);
-            enc.set(word, (int32_t)enc.size());           // len(encoder) BEFORE the insertion (what follows the last space is ignored)
+            // what follows the last space is ignored by the reference; when it is a number (the bundled vocab: the word's corpus
+            // count) it is kept as a placement HINT for the whole-word table (its most frequent words share a few lines)
+            uint64_t cnt = 0;
+            bool digits = k > a && cut + 1 < b;
+            for (size_t q = cut + 1; q < b && digits; ++q) {
+                if (vtext[q] < '0' || vtext[q] > '9' || cnt > (1ull << 56)) digits = false;
+                else cnt = cnt * 10 + (uint64_t)(vtext[q] - '0');
+            }
+            enc.set(word, (int32_t)enc.size(), digits ? cnt : 0);       // len(encoder) BEFORE the insertion
             i = (j < n) ? j + 1 : j;
         }
     }
     T.enc_words = enc.keys;
     T.enc_ids = enc.vals;
+    T.enc_count = enc.aux;
     for (int i = 0; i < 5; ++i) T.special_ids[i] = *enc.get(specials[i]);
     const int32_t unk_id = T.special_ids[4];
 
@@ -363,7 +372,7 @@ int gz_build_tables(const uint8_t* vocab, size_t vocab_len, const uint8_t* bpe, 
 // seed: adversarial tables only) are inserted by linear probing and their bucket is marked GZ_PH_OVERFLOW.
 // ---------------------------------------------------------------------------------------------------------------------
 void gz_ph_build(size_t n, void (*hashes)(const void* ctx, size_t i, uint32_t k1, uint32_t k2, uint32_t* ha, uint32_t* hb), const void* ctx,
-                 GzPhHost& out, std::vector<uint32_t>& slot_of)
+                 GzPhHost& out, std::vector<uint32_t>& slot_of, const uint8_t* hot, uint32_t hot_slots)
 {
     size_t slots = 16;
     while (slots * 4 < n * 5) slots <<= 1;                         // load <= 0.8
@@ -372,6 +381,7 @@ void gz_ph_build(size_t n, void (*hashes)(const void* ctx, size_t i, uint32_t k1
     size_t nb0 = 16;
     while (nb0 * 8 < n) nb0 <<= 1;
     static const int force = [] { const char* e = getenv("GZ_PH_FORCE_OVERFLOW"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
+    const uint32_t hzone = (hot && hot_slots < slots / 4) ? hot_slots : 0u;        // (a region that is a large part of the table steers nothing)
     GzPhHost best;
     std::vector<uint32_t> best_slots;
     bool have = false;
@@ -404,20 +414,26 @@ void gz_ph_build(size_t n, void (*hashes)(const void* ctx, size_t i, uint32_t k1
             bool placed = false;
             if (!(force && nonempty % (size_t)force == 0)) {
                 tmp.resize(hi - lo);
-                for (uint32_t d = 0; d < GZ_PH_OVERFLOW && !placed; ++d) {
-                    bool ok = true;
-                    for (uint32_t k = lo; k < hi && ok; ++k) {
-                        const uint32_t sl = gz_ph_slot(hb[keys[k]], d, sshift);
-                        if (used[sl]) ok = false;
-                        else { for (uint32_t j = lo; j < k; ++j) if (tmp[j - lo] == sl) { ok = false; break; } }
-                        tmp[k - lo] = sl;
+                // the hot region [0, hzone): a hot key must land inside, any other key outside.  A bucket that cannot be placed
+                // that way (two hot keys, a full region) is placed with its hot keys treated like the others.
+                bool any_hot = false;
+                if (hzone) for (uint32_t k = lo; k < hi; ++k) any_hot |= hot[keys[k]] != 0;
+                for (int pass = any_hot ? 0 : 1; pass < 2 && !placed; ++pass)
+                    for (uint32_t d = 0; d < GZ_PH_OVERFLOW && !placed; ++d) {
+                        bool ok = true;
+                        for (uint32_t k = lo; k < hi && ok; ++k) {
+                            const uint32_t sl = gz_ph_slot(hb[keys[k]], d, sshift);
+                            const bool want_in = pass == 0 && hot[keys[k]] != 0;
+                            if (used[sl] || (sl < hzone) != want_in) ok = false;
+                            else { for (uint32_t j = lo; j < k; ++j) if (tmp[j - lo] == sl) { ok = false; break; } }
+                            tmp[k - lo] = sl;
+                        }
+                        if (ok) {
+                            for (uint32_t k = lo; k < hi; ++k) { used[tmp[k - lo]] = 1; cur_slots[keys[k]] = tmp[k - lo]; }
+                            cur.disp[b] = (uint16_t)d;
+                            placed = true;
+                        }
                     }
-                    if (ok) {
-                        for (uint32_t k = lo; k < hi; ++k) { used[tmp[k - lo]] = 1; cur_slots[keys[k]] = tmp[k - lo]; }
-                        cur.disp[b] = (uint16_t)d;
-                        placed = true;
-                    }
-                }
             }
             if (!placed) { cur.disp[b] = (uint16_t)GZ_PH_OVERFLOW; for (uint32_t k = lo; k < hi; ++k) spill.push_back(keys[k]); }
         }
