@@ -112,7 +112,7 @@ struct gz_ctx {
 
     DBuf t_words2;                                           // long-key whole-word table (17..32 bytes)
     DBuf t_pair8, t_pair_disp, t_words0p, t_word0_disp;      // the perfectly hashed tables (gz_common.h)
-    DBuf t_pair_hot;                                         // hot set the merge kernel stages in LDS
+    DBuf t_pair_hot, t_word_hot;                             // hot sets the merge / word kernels stage in LDS
     struct TextWs { DBuf brk, st, en, blkcnt, docw0, wtok, waux, mtok, mlist, blkmiss, tilecnt, wlist, grpblk, lookback, mq; } tw[2][2];
     uint32_t lb_epoch = 0;               // call number of the chained scan (gz_split_kernel)   // [slot][text]
     hipStream_t stream2 = nullptr;       // sub-batches alternate between the two streams
@@ -608,7 +608,8 @@ static int build_word_table(gz_ctx* c, WordImages& W)
         // table's first lines: a hint to the builder, see gz_ph_build
         const uint32_t hot_slots = gz_word_hot_slots();
         std::vector<uint8_t> hotf;
-        if (hot_slots) {
+        std::vector<std::pair<uint64_t, uint32_t>> by_weight;       // (weight, index into found1), heaviest first
+        {
             std::unordered_map<std::string, uint64_t> weight;
             bool any = false;
             for (uint64_t h : H.enc_count) if (h) { any = true; break; }
@@ -622,14 +623,25 @@ static int build_word_table(gz_ctx* c, WordImages& W)
                 order[i] = {it == weight.end() ? 0 : it->second, (uint32_t)i};
             }
             std::sort(order.begin(), order.end(), [](const std::pair<uint64_t, uint32_t>& x, const std::pair<uint64_t, uint32_t>& y) { return x.first != y.first ? x.first > y.first : x.second < y.second; });
-            hotf.assign(found1.size(), 0);
-            const size_t nhot = std::min<size_t>(found1.size(), (size_t)hot_slots * 7 / 8);     // (an eighth of the region stays free: the last ones still find a slot)
-            for (size_t i = 0; i < nhot; ++i) hotf[order[i].second] = 1;
+            if (hot_slots) {
+                hotf.assign(found1.size(), 0);
+                const size_t nhot = std::min<size_t>(found1.size(), (size_t)hot_slots * 7 / 8);     // (an eighth of the region stays free: the last ones still find a slot)
+                for (size_t i = 0; i < nhot; ++i) hotf[order[i].second] = 1;
+            }
+            by_weight = std::move(order);
         }
         GzPhHost& ph = W.ph;
         gz_ph_build(found1.size(), hashes, &found1, ph, slot_of, hotf.empty() ? nullptr : hotf.data(), hot_slots);
         W.tabp.assign(ph.slots, GzWordSlot1{});
         for (size_t i = 0; i < found1.size(); ++i) W.tabp[slot_of[i]] = found1[i];
+        // the word kernel's LDS hot set: direct-mapped by the top bits of ha (the seeds the builder settled on), heaviest first
+        W.hot.assign(GZ_WORD_HOT_SLOTS, GzWordHot{{0, 0, 0}, 0});
+        for (const auto& o : by_weight) {
+            const GzWordSlot1& e = found1[o.second];
+            if ((e.meta & 31u) > 12u) continue;
+            GzWordHot& h = W.hot[gz_word1_ha(gz_slot1_lo(e), gz_slot1_hi(e), e.meta & 31u, ph.k1, ph.k2) >> GZ_WORD_HOT_SHIFT];
+            if (h.meta == 0) h = GzWordHot{{e.k[0], e.k[1], e.k[2]}, e.meta};
+        }
     }
     if (!found2.empty()) {
         size_t slots2 = 16;
@@ -651,13 +663,14 @@ static int install_word_tables(gz_ctx* c, const WordImages& W)
 {
     int rc;
     if (W.tabp.empty()) return GZ_OK;
-    if ((rc = upload(c, c->t_words0p, W.tabp)) || (rc = upload(c, c->t_word0_disp, W.ph.disp))) return rc;
+    if ((rc = upload(c, c->t_words0p, W.tabp)) || (rc = upload(c, c->t_word0_disp, W.ph.disp)) || (rc = upload(c, c->t_word_hot, W.hot))) return rc;
     if (!W.tab2.empty() && (rc = upload(c, c->t_words2, W.tab2))) return rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));                  // (the images may die once this returns)
     GzDeviceTables& D = c->dev;
     D.words0p = (const GzWordSlot1*)c->t_words0p.p;
     D.word0_ph = GzPh{(const uint16_t*)c->t_word0_disp.p, W.ph.nbuckets, W.ph.bshift, W.ph.sshift, W.ph.slots - 1, W.ph.k1, W.ph.k2};
     D.word0_ovf = W.ph.n_overflow;
+    D.word_hot = (const GzWordHot*)c->t_word_hot.p;
     if (!W.tab2.empty()) { D.words2 = (const GzWordSlot2*)c->t_words2.p; D.word2_mask = (uint32_t)W.tab2.size() - 1; }
     HIPCHK(c, hipMemcpy(c->t_struct.p, &c->dev, sizeof(GzDeviceTables), hipMemcpyHostToDevice));
     c->n_words = W.n_words;
@@ -742,7 +755,7 @@ void gz_destroy(gz_ctx* c)
     for (DBuf* b : {&c->w_pp[0], &c->w_pp[1], &c->w_ppoff[0], &c->w_ppoff[1], &c->w_pplen, &c->w_ppaux, &c->w_pp_in, &c->w_pp_inoff}) release(*b);
     for (DBuf* b : {&c->t_dec_entries, &c->t_dec_bytes, &c->w_dec_ids, &c->w_dec_roff, &c->w_dec_rb, &c->w_dec_ooff, &c->w_dec_out}) release(*b);
     if (c->comm && g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
-    for (DBuf* b : {&c->t_pair8, &c->t_pair_disp, &c->t_words0p, &c->t_word0_disp, &c->t_pair_hot}) release(*b);
+    for (DBuf* b : {&c->t_pair8, &c->t_pair_disp, &c->t_words0p, &c->t_word0_disp, &c->t_pair_hot, &c->t_word_hot}) release(*b);
     for (DBuf* b : {&c->t_merges, &c->t_symids, &c->t_bmp, &c->t_astral, &c->t_struct, &c->t_words2, &c->w_text, &c->w_toff, &c->w_pair,
                     &c->w_poff, &c->w_ids, &c->w_mask, &c->w_tt, &c->w_seq, &c->w_rowoff, &c->w_rowlen, &c->w_pairlen,
                     &c->w_nreal, &c->w_status, &c->w_raw, &c->w_arena, &c->w_flags, &c->w_word, &c->w_wordout})
@@ -813,6 +826,7 @@ int gz_load_tables(gz_ctx* c, const uint8_t* vocab, size_t vocab_len, const uint
     D.words0p = nullptr; D.word0_ph = GzPh{nullptr, 16, 28, 28, 15, 1, 1};
     D.pair_ovf = H.pair_ph.n_overflow; D.word0_ovf = 0;
     D.pair_hot = (const GzPair8*)c->t_pair_hot.p; D.pair_hot_shift = GZ_PAIR_HOT_SHIFT;
+    D.word_hot = nullptr;
     if (c->host.enc_words.size() >= (1u << 26)) return fail(c, GZ_E_LIMIT, "vocab has 2^26 or more entries");
     if ((rc = ensure(c, c->t_struct, sizeof(GzDeviceTables)))) return rc;
     HIPCHK(c, hipMemcpy(c->t_struct.p, &c->dev, sizeof(GzDeviceTables), hipMemcpyHostToDevice));
@@ -866,7 +880,8 @@ int gz_table_digest(gz_ctx* c, uint8_t out[32])
         (rc = add(D.pair_hot, GZ_PAIR_HOT_SLOTS * sizeof(GzPair8))) ||
         (rc = add(D.words2, D.words2 ? ((size_t)D.word2_mask + 1) * sizeof(GzWordSlot2) : 0)) ||
         (rc = add(D.words0p, D.words0p ? ((size_t)D.word0_ph.mask + 1) * sizeof(GzWordSlot1) : 0)) ||
-        (rc = add(D.word0_ph.disp, D.words0p ? (size_t)D.word0_ph.nbuckets * 2 : 0)))
+        (rc = add(D.word0_ph.disp, D.words0p ? (size_t)D.word0_ph.nbuckets * 2 : 0)) ||
+        (rc = add(D.word_hot, D.word_hot ? GZ_WORD_HOT_SLOTS * sizeof(GzWordHot) : 0)))
         return rc;
     const uint32_t scal[] = {D.n_ranks, D.n_symbols, D.astral_mask, (uint32_t)D.pad_id, (uint32_t)D.bos_id, (uint32_t)D.eos_id,
                              (uint32_t)D.unk_id, D.word2_mask, D.pair_ph.nbuckets, D.pair_ph.bshift, D.pair_ph.sshift, D.pair_ph.mask,

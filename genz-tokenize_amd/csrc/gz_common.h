@@ -65,6 +65,7 @@ constexpr uint32_t GZ_PH_MUL = 0x2C1B3C6Du;
 constexpr uint32_t GZ_PH_OVERFLOW = 0xFFFFu;
 constexpr uint32_t GZ_PH_LDS_BUCKETS = 16384;                 // displacement entries a workgroup stages in LDS (32 KB)
 constexpr uint32_t GZ_PAIR_HOT_SLOTS = 4096, GZ_PAIR_HOT_SHIFT = 20;      // 32 KB of LDS
+constexpr uint32_t GZ_WORD_HOT_SLOTS = 1024, GZ_WORD_HOT_SHIFT = 22;      // 16 KB of LDS: the word kernel's hot words (16-byte entries)
 struct GzPh {
     const uint16_t* disp;                                     // [nbuckets] (device copy)
     uint32_t nbuckets, bshift;                                // bucket = ha >> bshift      (nbuckets = 2^(32 - bshift) >= 16)
@@ -106,6 +107,7 @@ GZ_HD uint32_t gz_word_hash2(const uint64_t k[4], uint32_t len)
 // a slot answer a word of <= 12 bytes (97 % of the probes): one 16-byte load per lane; only lanes with a longer word load the
 // slot's fifth dword (a wave's scattered loads cost the CU's L1 a look-up per lane and load: 128 per round before, ~ 67 now).
 struct GzWordSlot1 { uint32_t k[3]; uint32_t meta; uint32_t k3; uint32_t pad[3]; };
+struct GzWordHot { uint32_t k[3]; uint32_t meta; };         // a hot word: the first 16 bytes of its GzWordSlot1 (meta 0: empty)
 GZ_HD uint64_t gz_slot1_lo(const GzWordSlot1& e) { return (uint64_t)e.k[0] | ((uint64_t)e.k[1] << 32); }
 GZ_HD uint64_t gz_slot1_hi(const GzWordSlot1& e) { return (uint64_t)e.k[2] | ((uint64_t)e.k3 << 32); }
 // The hashes of such a key, from ONE mix h0 (four multiplies, three xors) with the builder's seeds k1, k2:
@@ -158,6 +160,10 @@ struct GzDeviceTables {
     // hot set of the merge kernel, staged in LDS (same entry layout, direct-mapped, slot = top bits of ha): a probe that
     // hits there costs no memory traffic -- a random probe of a table in L2 moves a whole 128-byte line for 8 bytes
     const GzPair8*     pair_hot;    uint32_t pair_hot_shift;  // [2^(32 - shift)] the most frequent merges (smallest ranks)
+    // hot words of the word kernel, staged in LDS: the first 16 bytes of a whole-word slot (key bytes 0..11, len | id << 5; keys of
+    // <= 12 bytes only), direct-mapped by the top bits of ha; the most frequent word keeps a contested place.  A SUBSET of
+    // words0p: it changes where a probe is answered, never what it answers.
+    const GzWordHot*   word_hot;                              // [GZ_WORD_HOT_SLOTS]
 };
 
 // Host side of a perfect hash: hashes in, displacement array + the slot of every key out (gz_tables.cpp).
