@@ -746,8 +746,10 @@ def sum64(p):
 HDR = 56                                                                         # magic, layout, key[32], payload_len, payload_sum
 payload = bytearray(good[HDR:])
 assert sum64(bytes(payload)) == struct.unpack_from("<Q", good, 48)[0]             # (this Python restatement of the checksum is right)
-nb = struct.unpack_from("<I", payload, len(payload) - 8 - 28)[0]                  # nbuckets of the word table's perfect hash
-meta_at = len(payload) - 8 - 28 - (8 + 2 * nb) - 32 + 12
+tail = 8 + (8 + 1024 * 16)                                                        # n_words, the LDS hot words (count + 1 024 entries of 16 bytes)
+assert struct.unpack_from("<Q", payload, len(payload) - tail)[0] == 1024
+nb = struct.unpack_from("<I", payload, len(payload) - tail - 28)[0]               # nbuckets of the word table's perfect hash
+meta_at = len(payload) - tail - 28 - (8 + 2 * nb) - 32 + 12
 meta = struct.unpack_from("<I", payload, meta_at)[0]
 assert 1 <= (meta & 31) <= 16
 struct.pack_into("<I", payload, meta_at, (meta & ~31) | 31)
