@@ -629,6 +629,45 @@ def test_long_and_huge_words(tok, oracle_tables):
     _compare_batch(out, O.call_batch(oracle_tables, docs, pairs, None, True, True), True)
 
 
+def test_bytes_that_are_not_utf8_stay_inside_their_document(tok, sampler):
+    """Input outside the contract (the C ABI takes raw bytes): documents full of stray continuation bytes, truncated and
+    over-long sequences sit BETWEEN well-formed documents.  What they tokenize to is not specified -- but their words must
+    not spill into a neighbour's tokens (the merge kernel reserves token places from a lead-byte count; a code point that
+    starts at a continuation byte takes the wave-cooperative path instead), the call must not fault, and two runs must agree.
+    The well-formed documents must come out exactly as in a batch without the bad ones, whole-word tables on and off, through
+    the big pipeline and the one-launch kernel."""
+    import random
+    text, offs, _ = corpus.config_corpus(3, n_docs=3000, seed=91, sampler=sampler)
+    raw = text.tobytes()
+    r = random.Random(17)
+    def junk():
+        n = r.choice([1, 2, 3, 5, 8, 13, 16, 17, 31, 40, 70, 200])
+        pool = [b"\x80", b"\xbf", b"\x9a", b"a", b"\xe1", b"\xe1\xba", b"\xf0\x9f", b"\xc3", b"\xc2\xa0", b" ", b"\n", b"ng", b"\xe1\xbb\x87", b"\xff", b"\xc0\x80"]
+        return b"".join(r.choice(pool) for _ in range(n))
+    docs, good = [], []
+    for i in range(len(offs) - 1):
+        if r.random() < 0.3:
+            docs.append(junk())
+        good.append(len(docs))
+        docs.append(raw[offs[i]:offs[i + 1]])
+    docs.append(junk())
+    mixed = np.frombuffer(b"".join(docs), dtype=np.uint8)
+    moffs = np.concatenate([[0], np.cumsum([len(d) for d in docs])]).astype(np.int64)
+    for wt in (True, False):
+        for ml in (48, 256):
+            want = tok.encode_packed(text, offs, max_len=ml, word_table=wt)
+            a = tok.encode_packed(mixed, moffs, max_len=ml, word_table=wt)
+            b = tok.encode_packed(mixed, moffs, max_len=ml, word_table=wt)
+            assert np.array_equal(a["input_ids"], b["input_ids"]) and np.array_equal(a["attention_mask"], b["attention_mask"])
+            assert np.array_equal(a["input_ids"][good], want["input_ids"]) and np.array_equal(a["attention_mask"][good], want["attention_mask"])
+    # small batches take the one-launch kernel: the same property on the first documents
+    k = 40
+    sm = tok.encode_packed(mixed[:moffs[k]], moffs[:k + 1], max_len=32)
+    gk = [g for g in good if g < k]
+    ref = tok.encode_packed(text[:offs[len(gk)]], offs[:len(gk) + 1], max_len=32)
+    assert np.array_equal(sm["input_ids"][gk], ref["input_ids"])
+
+
 def test_deterministic(tok, sampler):
     text, offs, L = corpus.config_corpus(3, n_docs=20000, seed=21, sampler=sampler)
     a = tok.encode_packed(text, offs, max_len=L)
