@@ -68,7 +68,8 @@ echo "(5)" >> $O/progress.txt
 # (6)
 ( cd $R && python3 tools/t_load.py > $O/table_load.txt 2>&1; python3 tools/small_bench.py > $O/small_calls.txt 2>&1 )
 echo "(6)" >> $O/progress.txt
-# (7)
+# (7) (the traffic files go where bench.py looks for them: this run's line then carries them)
+cp $O/pmc_traffic.json $R/profiles/r04_pmc_traffic.json; cp $O/pmc_traffic_shard.json $R/profiles/r04_pmc_traffic_shard.json; cp $O/pmc_traffic_cfg4.json $R/profiles/r04_pmc_traffic_cfg4.json
 ( cd $R && timeout -k 10 900 python3 bench.py > $O/bench.json.log 2> $O/bench.err ) || { tail -5 $O/bench.err; exit 1; }
 tail -c 400 $O/bench.json.log
 find $O -name "*counter_collection.csv" -delete
