@@ -73,13 +73,16 @@ __device__ __forceinline__ int wave_sum(int v)
 // bucket's displacement (16 KB array in memory: the kernels that call this are latency-bound chains, not the big pipeline's
 // merge kernel, which stages it in LDS) -> ONE 8-byte load; the key is compared in full.  Returns the rank (GZ_RANK_NONE:
 // no such merge) and the merged symbol: the rank itself unless another line spells the same string (alias flag).
-__device__ __forceinline__ uint32_t probe_pair(const GzDeviceTables& T, uint32_t a, uint32_t b, uint32_t& merged)
+// (ldisp: a copy of the displacement array in LDS, or nullptr: read it from memory)
+__device__ __forceinline__ uint32_t probe_pair(const GzDeviceTables& T, uint32_t a, uint32_t b, uint32_t& merged, const uint16_t* ldisp = nullptr)
 {
     typedef unsigned __attribute__((ext_vector_type(2))) v2u;
     typedef const v2u __attribute__((address_space(1)))* gp8_t;
     typedef const uint16_t __attribute__((address_space(1)))* g16_t;
+    typedef const uint16_t __attribute__((address_space(3)))* l16_t;
     if ((a | b) & 0xFFF00000u) return GZ_RANK_NONE;          // a code point outside every table never merges
-    const uint32_t d = ((g16_t)T.pair_ph.disp)[gz_pair_ha(a, b, T.pair_ph.k1, T.pair_ph.k2) >> T.pair_ph.bshift];
+    const uint32_t bucket = gz_pair_ha(a, b, T.pair_ph.k1, T.pair_ph.k2) >> T.pair_ph.bshift;
+    const uint32_t d = ldisp ? ((l16_t)ldisp)[bucket] : ((g16_t)T.pair_ph.disp)[bucket];
     uint32_t h = gz_ph_slot(gz_pair_hb(a, b), d, T.pair_ph.sshift);
     const uint32_t klo = a | (b << 20), khi = b >> 12;
     v2u q = ((gp8_t)T.pair8)[h];
