@@ -46,11 +46,12 @@ PIPELINE = ("gz_classify, gz_scan32, gz_words2, gz_scan32 (misses), gz_mpre, gz_
 
 
 def kernel_source_sha16():
-    """sha256 (first 16 hex digits) over the native sources: a PMC profile is only quoted for the build it was taken on."""
+    """sha256 (first 16 hex digits) over the KERNEL sources (the .hip / .inc files and the two headers they share with the host
+    side: kernels, launch shapes, table layouts): a PMC profile is only quoted for the kernels it was taken on."""
     h = hashlib.sha256()
     d = os.path.join(ROOT, "genz-tokenize_amd", "csrc")
     for name in sorted(os.listdir(d)):
-        if name.endswith((".hip", ".inc", ".h", ".cpp")):
+        if name.endswith((".hip", ".inc")) or name in ("gz_kernels.h", "gz_common.h"):
             h.update(name.encode()); h.update(open(os.path.join(d, name), "rb").read())
     return h.hexdigest()[:16]
 

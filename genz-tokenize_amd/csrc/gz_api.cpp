@@ -9,6 +9,7 @@
 #include <cstring>
 #include <cstdlib>
 #include <atomic>
+#include <chrono>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -781,6 +782,14 @@ int gz_load_tables(gz_ctx* c, const uint8_t* vocab, size_t vocab_len, const uint
     if (c->pend.active) { int rc = sync_locked(c); if (rc) return rc; }
     c->have_tables = false;
     int rc = GZ_OK;
+    static const bool load_timing = getenv("GZ_LOAD_TIMING") != nullptr;    // phase times of this call on stderr (tools/t_load.py)
+    auto t_last = std::chrono::steady_clock::now();
+    auto phase = [&](const char* what) {
+        if (!load_timing) return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "gz_load_tables: %-34s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+        t_last = t;
+    };
     static const uint8_t empty = 0;
     if (!vocab) vocab = &empty;
     if (!bpe) bpe = &empty;
@@ -806,6 +815,7 @@ int gz_load_tables(gz_ctx* c, const uint8_t* vocab, size_t vocab_len, const uint
         return fail(c, GZ_E_INVALID, "unexpected failure while building tables");
     }
     if (rc) return rc;
+    phase(hit ? "cache read" : "host build (gz_build_tables)");
     GzHostTables& H = c->host;
     if ((rc = upload(c, c->t_merges, H.merges))) return rc;
     if ((rc = upload(c, c->t_symids, H.sym_ids))) return rc;
@@ -831,16 +841,20 @@ int gz_load_tables(gz_ctx* c, const uint8_t* vocab, size_t vocab_len, const uint
     if ((rc = ensure(c, c->t_struct, sizeof(GzDeviceTables)))) return rc;
     HIPCHK(c, hipMemcpy(c->t_struct.p, &c->dev, sizeof(GzDeviceTables), hipMemcpyHostToDevice));
     c->have_tables = true;
+    phase("upload of the pair / symbol tables");
     if (!hit) {
         rc = build_word_table(c, W);                             // (runs the GPU merge path over every candidate word)
         if (rc) { c->have_tables = false; return rc; }
+        phase("whole-word tables (GPU merge path + perfect hash)");
     }
     rc = install_word_tables(c, W);
     if (rc) { c->have_tables = false; return rc; }
+    phase("upload of the whole-word tables");
     if (!hit && !cpath.empty()) {
         bool written = false;
         try { written = cache_write(cdir, cpath, key, c->host, W); } catch (...) { /* a cache that cannot be written is only a slower start */ }
         if (!written) c->cache_status = 4;                       // 4: rebuilt, and the file could NOT be written (directory missing / shared / full)
+        phase("cache write");
     }
     return GZ_OK;
 }

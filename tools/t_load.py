@@ -21,6 +21,7 @@ def timed(make):
 
 
 os.environ["GZ_TABLE_CACHE"] = "off"
+os.environ["GZ_LOAD_TIMING"] = "1"           # (read once, at the first load: the library prints the phases of every gz_load_tables to stderr)
 tok, first = timed(Tokenize)
 print("import %.3f s; first Tokenize() %.3f s (HIP runtime start-up included)" % (t1 - t0, first))
 _, nocache = timed(Tokenize)
