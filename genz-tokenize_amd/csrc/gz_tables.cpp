@@ -116,23 +116,80 @@ bool ends_with(const std::string& s, const char* suf)
     return s.size() >= k && std::memcmp(s.data() + s.size() - k, suf, k) == 0;
 }
 
+// string -> its index in a vector of strings the caller keeps (open addressing, cached hashes: the loader makes half a
+// million dictionary operations on short strings; std::unordered_map<std::string, ...> spent most of the table build in
+// allocations and bucket walks)
+struct StrIndex {
+    std::vector<uint32_t> slot;   // index + 1 (0: empty)
+    std::vector<uint32_t> hsh;
+    size_t n = 0;
+    static uint32_t hash(const char* p, size_t len)
+    {
+        uint64_t h = 0x9E3779B97F4A7C15ull ^ (len * 0xFF51AFD7ED558CCDull);
+        while (len >= 8) { uint64_t v; std::memcpy(&v, p, 8); h = (h ^ v) * 0xC2B2AE3D27D4EB4Full; h ^= h >> 29; p += 8; len -= 8; }
+        uint64_t v = 0;
+        if (len) std::memcpy(&v, p, len);
+        h = (h ^ v) * 0x9FB21C651E98DF25ull;
+        h ^= h >> 32;
+        return (uint32_t)h | 1u;                                  // (never 0)
+    }
+    void reserve(size_t k)
+    {
+        size_t cap = 16;
+        while (cap < 2 * k + 2) cap <<= 1;
+        if (cap > slot.size()) rebuild(cap);
+    }
+    void rebuild(size_t cap)
+    {
+        std::vector<uint32_t> os, oh;
+        os.swap(slot); oh.swap(hsh);
+        slot.assign(cap, 0); hsh.assign(cap, 0);
+        for (size_t i = 0; i < os.size(); ++i) if (os[i]) place(oh[i], os[i] - 1);
+    }
+    void place(uint32_t h, uint32_t idx)
+    {
+        size_t m = slot.size() - 1, q = h & m;
+        while (slot[q]) q = (q + 1) & m;
+        slot[q] = idx + 1; hsh[q] = h;
+    }
+    // index of the key, or UINT32_MAX
+    uint32_t find(const std::vector<std::string>& keys, const char* p, size_t len, uint32_t h) const
+    {
+        if (slot.empty()) return 0xFFFFFFFFu;
+        size_t m = slot.size() - 1, q = h & m;
+        while (slot[q]) {
+            if (hsh[q] == h) { const std::string& k = keys[slot[q] - 1]; if (k.size() == len && std::memcmp(k.data(), p, len) == 0) return slot[q] - 1; }
+            q = (q + 1) & m;
+        }
+        return 0xFFFFFFFFu;
+    }
+    void insert(uint32_t h, uint32_t idx)                         // (the key is not in the index)
+    {
+        if (2 * (n + 1) + 2 > slot.size()) rebuild(slot.empty() ? 16 : slot.size() * 2);
+        place(h, idx);
+        ++n;
+    }
+};
+
 struct OrderedDict {            // a Python dict[str, int]: insertion order, overwrite keeps position
-    std::unordered_map<std::string, size_t> pos;
+    StrIndex pos;
     std::vector<std::string> keys;
     std::vector<int32_t> vals;
     std::vector<uint64_t> aux;  // a second value per key that is NOT part of the dict (a hint / a field count): the last set() wins
     void reserve(size_t n) { pos.reserve(n); keys.reserve(n); vals.reserve(n); aux.reserve(n); }
     void set(const std::string& k, int32_t v, uint64_t a = 0)
     {
-        auto it = pos.find(k);
-        if (it == pos.end()) { pos.emplace(k, keys.size()); keys.push_back(k); vals.push_back(v); aux.push_back(a); }
-        else { vals[it->second] = v; aux[it->second] = a; }
+        const uint32_t h = StrIndex::hash(k.data(), k.size());
+        const uint32_t i = pos.find(keys, k.data(), k.size(), h);
+        if (i == 0xFFFFFFFFu) { pos.insert(h, (uint32_t)keys.size()); keys.push_back(k); vals.push_back(v); aux.push_back(a); }
+        else { vals[i] = v; aux[i] = a; }
     }
-    const int32_t* get(const std::string& k) const
+    const int32_t* get(const char* p, size_t len) const
     {
-        auto it = pos.find(k);
-        return it == pos.end() ? nullptr : &vals[it->second];
+        const uint32_t i = pos.find(keys, p, len, StrIndex::hash(p, len));
+        return i == 0xFFFFFFFFu ? nullptr : &vals[i];
     }
+    const int32_t* get(const std::string& k) const { return get(k.data(), k.size()); }
     size_t size() const { return keys.size(); }
 };
 
@@ -241,38 +298,49 @@ int gz_build_tables(const uint8_t* vocab, size_t vocab_len, const uint8_t* bpe, 
     // smaller rank), so that a pair-table entry needs no separate "merged symbol" field; every other string (merge
     // operands that no merge produces, single characters) is numbered from the number of lines up.  Ranks of lines that
     // are no merges stay unused ids (empty strings).
-    std::unordered_map<std::string, uint32_t> sym_of;
     const size_t n_lines = T.merges.size();
-    sym_of.reserve(2 * n_lines + 1024);
     struct Pair { uint32_t a, b, rank; };
     std::vector<Pair> pairs;
-    struct Fields { std::string a, b, m; uint32_t rank; };       // first, second, first + second (tokenize.py:88)
+    struct Fields { uint32_t key, nl, rank; };                  // a two-field line: its key (first '\n' second), where the '\n' is, its rank
     std::vector<Fields> two;
     two.reserve(T.rank_keys.size());
+    // the strings the merges produce (first + second, tokenize.py:88), each with the smallest rank that spells it
+    std::vector<std::string> mstr;
+    std::vector<uint32_t> mrank;
+    StrIndex midx;
+    mstr.reserve(n_lines); mrank.reserve(n_lines); midx.reserve(n_lines);
+    std::string m;
     for (size_t k = 0; k < T.rank_keys.size(); ++k) {
         if (T.rank_nfields[k] != 2) continue;             // such a key can never equal a (first, second) pair
         const std::string& key = T.rank_keys[k];
-        size_t nl = key.find('\n');
-        two.push_back(Fields{key.substr(0, nl), key.substr(nl + 1), std::string(), (uint32_t)T.rank_vals[k]});
-        two.back().m.reserve(key.size());
-        two.back().m.append(two.back().a).append(two.back().b);
-        const std::string& m = two.back().m;
-        auto it = sym_of.find(m);
-        if (it == sym_of.end()) sym_of.emplace(m, two.back().rank);
-        else if (two.back().rank < it->second) it->second = two.back().rank;
+        const size_t nl = key.find('\n');
+        two.push_back(Fields{(uint32_t)k, (uint32_t)nl, (uint32_t)T.rank_vals[k]});
+        m.assign(key, 0, nl).append(key, nl + 1, std::string::npos);
+        const uint32_t h = StrIndex::hash(m.data(), m.size());
+        const uint32_t i = midx.find(mstr, m.data(), m.size(), h);
+        if (i == 0xFFFFFFFFu) { midx.insert(h, (uint32_t)mstr.size()); mstr.push_back(m); mrank.push_back(two.back().rank); }
+        else if (two.back().rank < mrank[i]) mrank[i] = two.back().rank;
     }
     T.symbols.assign(n_lines, std::string());
-    for (const auto& kv : sym_of) T.symbols[kv.second] = kv.first;
-    auto intern = [&](const std::string& s) -> uint32_t {
-        auto it = sym_of.find(s);
-        if (it != sym_of.end()) return it->second;
-        uint32_t id = (uint32_t)T.symbols.size();
-        sym_of.emplace(s, id);
-        T.symbols.push_back(s);
+    StrIndex sidx;                                                // symbol string -> symbol id (the strings live in T.symbols)
+    sidx.reserve(2 * n_lines + 1024);
+    for (size_t i = 0; i < mstr.size(); ++i) {
+        sidx.insert(StrIndex::hash(mstr[i].data(), mstr[i].size()), mrank[i]);
+        T.symbols[mrank[i]] = std::move(mstr[i]);
+    }
+    auto intern = [&](const char* p, size_t len) -> uint32_t {
+        const uint32_t h = StrIndex::hash(p, len);
+        const uint32_t i = sidx.find(T.symbols, p, len, h);
+        if (i != 0xFFFFFFFFu) return i;
+        const uint32_t id = (uint32_t)T.symbols.size();
+        sidx.insert(h, id);
+        T.symbols.emplace_back(p, len);
         return id;
     };
     for (const Fields& f : two) {
-        uint32_t ia = intern(f.a), ib = intern(f.b), im = intern(f.m);
+        const std::string& key = T.rank_keys[f.key];
+        m.assign(key, 0, f.nl).append(key, f.nl + 1, std::string::npos);
+        const uint32_t ia = intern(key.data(), f.nl), ib = intern(key.data() + f.nl + 1, key.size() - f.nl - 1), im = intern(m.data(), m.size());
         T.merges[f.rank] = GzMergeInfo{ia, ib, im, 0};
         pairs.push_back({ia, ib, f.rank});
     }
@@ -280,10 +348,10 @@ int gz_build_tables(const uint8_t* vocab, size_t vocab_len, const uint8_t* bpe, 
     // the non-final piece of symbol c
     for (const std::string& w : enc.keys) {
         if (w.empty()) continue;
-        if (count_cps(w) == 1) intern(w + "</w>");
+        if (count_cps(w) == 1) { m.assign(w).append("</w>"); intern(m.data(), m.size()); }
         if (ends_with(w, "@@") && w.size() > 2) {
-            std::string body = w.substr(0, w.size() - 2);
-            if (count_cps(body) == 1) intern(body);
+            m.assign(w, 0, w.size() - 2);
+            if (count_cps(m) == 1) intern(m.data(), m.size());
         }
     }
     if (T.symbols.size() > GZ_MAX_SYMBOLS) { err = "too many distinct symbols"; return GZ_E_LIMIT; }

@@ -36,5 +36,15 @@ print("cache miss: Tokenize() %.1f ms (status %d)" % (miss * 1e3, m._ctx.table_c
 print("cache hit:  Tokenize() %.1f ms, %.1f ms (status %d)   fromFile %.1f ms (status %d)" % (
     hit * 1e3, hit2 * 1e3, h._ctx.table_cache_status(), hit_ff * 1e3, ff._ctx.table_cache_status()))
 print("digests equal:", m._ctx.table_digest() == h._ctx.table_digest() == ff._ctx.table_digest())
+# where a construction spends its time outside gz_load_tables
+from genz_tokenize import _native as N
+t = [time.perf_counter()]
+ctx = N.Context(None); t.append(time.perf_counter())
+v = open(os.path.join(d, "vocab.txt"), encoding="utf-8").read(); b_ = open(os.path.join(d, "bpe.codes"), encoding="utf-8").read(); t.append(time.perf_counter())
+vb, bb = v.encode("utf-8"), b_.encode("utf-8"); t.append(time.perf_counter())
+os.environ["GZ_TABLE_CACHE"] = "off"
+ctx.load_tables(vb, bb, ("<pad>", "<s>", "</s>", "<mask>", "<unk>")); t.append(time.perf_counter())
+ctx.decoder_snapshot(); t.append(time.perf_counter())
+print("stages: Context() %.1f ms, read + decode both files %.1f ms, encode %.1f ms, load_tables (no cache) %.1f ms, decoder_snapshot %.1f ms" % tuple((t[i + 1] - t[i]) * 1e3 for i in range(5)))
 a = time.perf_counter(); _ = h.decoder; b = time.perf_counter()
 print("first .decoder access %.1f ms" % ((b - a) * 1e3))
