@@ -214,6 +214,15 @@ GzShape make_shape(int32_t max_len, uint32_t flags)
 
 // Enqueue every kernel of one call.  All pointers are device pointers.  Sub-batches alternate between two streams so
 // that the bandwidth-bound assemble kernel of one overlaps the issue-bound word / merge kernels of the next.
+// The second text stream and the side stream of the batch pipeline are made when a call first needs them (a stream costs
+// ~ 2.5 ms to create: a tokenizer that only ever sees small calls never pays for them).
+static int need_side_streams(gz_ctx* c, bool second)
+{
+    if (!c->side) HIPCHK(c, hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+    if (second && !c->stream2) HIPCHK(c, hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking));
+    return GZ_OK;
+}
+
 int enqueue(gz_ctx* c)
 {
     gz_ctx::Pending& p = c->pend;
@@ -240,6 +249,7 @@ int enqueue(gz_ctx* c)
                                                                 //  stream ~ 5 us between two launches)
     }
     const bool two = p.subs.size() > 1;
+    if (!p.subs.empty()) { int rs = need_side_streams(c, two); if (rs) return rs; }
     if (two) { HIPCHK(c, hipEventRecord(c->ev_fork, s)); HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0)); }
     if (p.small)
         gz_launch_small(T, p.s_text0, p.s_off, p.s_base, p.s_pair0, p.s_poff, p.s_pbase, p.s_docs, p.small_G, p.s_dense ? 1 : 0, p.s_max_len,
@@ -274,6 +284,7 @@ int enqueue(gz_ctx* c)
 // encode call touches the buffers again (enqueue waits for ev_x)
 int x_begin(gz_ctx* c)
 {
+    if (!c->xstream) HIPCHK(c, hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));      // (a stream costs ~ 2.5 ms to create: made when first needed)
     if (c->enc_seq > (uint64_t)c->x_back) HIPCHK(c, hipStreamWaitEvent(c->xstream, c->ev_tok[(c->enc_seq - 1 - (uint64_t)c->x_back) & 3], 0));
     return GZ_OK;
 }
@@ -553,6 +564,14 @@ static int encode_host_locked(gz_ctx* c, const uint8_t* text, const int64_t* tex
 // a word whose result is exactly [bos, id, eos] is recorded as word -> id.  Nothing is computed on the CPU.
 static int build_word_table(gz_ctx* c, WordImages& W)
 {
+    static const bool load_timing = getenv("GZ_LOAD_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto phase = [&](const char* what) {
+        if (!load_timing) return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "  word tables: %-34s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+        t_last = t;
+    };
     W = WordImages();
     GzHostTables& H = c->host;
     std::vector<uint8_t> text;
@@ -572,11 +591,13 @@ static int build_word_table(gz_ctx* c, WordImages& W)
     const int64_t cap = (int64_t)text.size() + 2 * n;
     std::vector<int32_t> ids((size_t)cap), mask((size_t)cap), nreal((size_t)n);
     std::vector<int64_t> row((size_t)n + 1);
+    phase("candidate words");
     c->building_words = true;
     int rc = encode_host_locked(c, text.data(), off.data(), nullptr, nullptr, n, 0, GZ_MAX_LEN_NONE | GZ_NO_WORD_TABLE, cap,
                                 ids.data(), mask.data(), nullptr, nullptr, row.data(), nullptr, nreal.data(), nullptr);
     c->building_words = false;
     if (rc) return rc;
+    phase("GPU merge path over the candidates");
     std::vector<GzWordSlot2> found2;                         // 17..32 bytes: the long-key table (probed once per miss)
     std::vector<GzWordSlot1> found1;                         // <= 16 bytes: perfectly hashed, one probe per word
     for (int64_t i = 0; i < n; ++i) {
@@ -607,21 +628,24 @@ static int build_word_table(gz_ctx* c, WordImages& W)
         };
         // the words running text consists of (by the counts the vocab file carries; without counts: the file's order) share the
         // table's first lines: a hint to the builder, see gz_ph_build
+        phase("results");
         const uint32_t hot_slots = gz_word_hot_slots();
         std::vector<uint8_t> hotf;
         std::vector<std::pair<uint64_t, uint32_t>> by_weight;       // (weight, index into found1), heaviest first
         {
-            std::unordered_map<std::string, uint64_t> weight;
+            // a recorded word's id IS its vocab entry's id (the GPU looked the whole word up): the weights go by id
             bool any = false;
             for (uint64_t h : H.enc_count) if (h) { any = true; break; }
-            weight.reserve(H.enc_words.size());
-            for (size_t i = 0; i < H.enc_words.size(); ++i) weight[H.enc_words[i]] = any ? H.enc_count[i] : (uint64_t)(H.enc_words.size() - i);
+            std::vector<uint64_t> weight_of_id(H.enc_words.size(), 0);          // (ids are sizes of the dict at insertion: < its size)
+            for (size_t i = 0; i < H.enc_words.size(); ++i) {
+                const int32_t id = H.enc_ids[i];
+                if (id >= 0 && (size_t)id < weight_of_id.size()) weight_of_id[(size_t)id] = any ? H.enc_count[i] : (uint64_t)(H.enc_words.size() - i);
+            }
+            const uint32_t unk = (uint32_t)H.special_ids[4];                    // (a word the vocab does not hold: no weight)
             std::vector<std::pair<uint64_t, uint32_t>> order(found1.size());
             for (size_t i = 0; i < found1.size(); ++i) {
-                char key[16];
-                std::memcpy(key, found1[i].k, 12); std::memcpy(key + 12, &found1[i].k3, 4);
-                auto it = weight.find(std::string(key, found1[i].meta & 31u));
-                order[i] = {it == weight.end() ? 0 : it->second, (uint32_t)i};
+                const uint32_t id = found1[i].meta >> 5;
+                order[i] = {(id == unk || id >= weight_of_id.size()) ? 0 : weight_of_id[id], (uint32_t)i};
             }
             std::sort(order.begin(), order.end(), [](const std::pair<uint64_t, uint32_t>& x, const std::pair<uint64_t, uint32_t>& y) { return x.first != y.first ? x.first > y.first : x.second < y.second; });
             if (hot_slots) {
@@ -631,8 +655,10 @@ static int build_word_table(gz_ctx* c, WordImages& W)
             }
             by_weight = std::move(order);
         }
+        phase("weights");
         GzPhHost& ph = W.ph;
         gz_ph_build(found1.size(), hashes, &found1, ph, slot_of, hotf.empty() ? nullptr : hotf.data(), hot_slots);
+        phase("perfect hash");
         W.tabp.assign(ph.slots, GzWordSlot1{});
         for (size_t i = 0; i < found1.size(); ++i) W.tabp[slot_of[i]] = found1[i];
         // the word kernel's LDS hot set: direct-mapped by the top bits of ha (the seeds the builder settled on), heaviest first
@@ -656,6 +682,7 @@ static int build_word_table(gz_ctx* c, WordImages& W)
         }
     }
     W.n_words = (int64_t)(found1.size() + found2.size());
+    phase("hot set, long-key table");
     return GZ_OK;
 }
 
@@ -688,6 +715,14 @@ int gz_create(int device_id, gz_ctx** out)
 {
     if (!out) return GZ_E_INVALID;
     *out = nullptr;
+    static const bool load_timing = getenv("GZ_LOAD_TIMING") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto phase = [&](const char* what) {
+        if (!load_timing) return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "gz_create: %-38s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(t - t_last).count());
+        t_last = t;
+    };
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     if (e != hipSuccess || n <= 0)
@@ -698,6 +733,7 @@ int gz_create(int device_id, gz_ctx** out)
     if (e != hipSuccess) return fail(nullptr, GZ_E_HIP, "hipGetDeviceProperties: %s", hipGetErrorString(e));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
         return fail(nullptr, GZ_E_NODEVICE, "device %d is %s; this library is built for gfx950 only", device_id, prop.gcnArchName);
+    phase("device count and properties");
     gz_ctx* c = new (std::nothrow) gz_ctx();
     if (!c) return fail(nullptr, GZ_E_NOMEM, "out of host memory");
     c->device = device_id;
@@ -707,21 +743,22 @@ int gz_create(int device_id, gz_ctx** out)
         return fail(nullptr, GZ_E_HIP, "stream / pinned memory creation failed");
     }
     std::memset(c->h_flags, 0, 64);
+    phase("device, first stream, pinned flags");
     if (const char* e = getenv("GZ_WORD_TABLE")) c->no_words_env = (e[0] == '0');
     for (auto& ev : c->ev) hipEventCreate(&ev);
-    hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking);
     hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
-    hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking);
-    hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
     for (auto& a : c->ev_sf0) for (auto& e : a) hipEventCreateWithFlags(&e, hipEventDisableTiming);
     for (auto& a : c->ev_sb) for (auto& e : a) hipEventCreateWithFlags(&e, hipEventDisableTiming);
     for (auto& a : c->ev_sf) for (auto& e : a) hipEventCreateWithFlags(&e, hipEventDisableTiming);
     for (auto& a : c->ev_sj) for (auto& e : a) hipEventCreateWithFlags(&e, hipEventDisableTiming);
     for (auto& e : c->ev_tok) hipEventCreateWithFlags(&e, hipEventDisableTiming);
     hipEventCreateWithFlags(&c->ev_x, hipEventDisableTiming);
+    phase("streams and events");
     hipHostMalloc((void**)&c->h_pick, 256, hipHostMallocDefault);
+    phase("pinned pick buffer");
     if (ensure(c, c->w_flags, 64) != GZ_OK) { g_create_err = c->err; gz_destroy(c); return GZ_E_NOMEM; }
+    phase("device flags");
     *out = c;
     return GZ_OK;
 }
@@ -1247,6 +1284,7 @@ int gz_encode_batch_csr(gz_ctx* c, const uint8_t* text, const int64_t* text_off,
     const int64_t* d_off = (const int64_t*)c->w_toff.p;
     const int use_words = use_words_flags(c, flags);
     hipStream_t s = c->stream;
+    if ((rc = need_side_streams(c, false))) return rc;
     // ---- everything the GPU has to do is enqueued first ...
     HIPCHK(c, hipMemcpyAsync(c->w_toff.p, text_off, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice, c->s_in));
     for (int k = 0; k < nsub; ++k) {

@@ -15,6 +15,7 @@
 #include "../../include/genz_tokenize.h"
 
 #include <algorithm>
+#include <thread>
 #include <cstring>
 #include <unordered_map>
 
@@ -207,52 +208,63 @@ int gz_build_tables(const uint8_t* vocab, size_t vocab_len, const uint8_t* bpe, 
                     const char* const specials[5], GzHostTables& T, std::string& err)
 {
     T = GzHostTables();
+    // The two files are independent until the symbols meet the vocabulary: the vocab side (decode, encoder) runs on a second
+    // thread beside the merge side (decode, bpe_ranks, the merges' symbols); later the pair table is hashed on a second thread
+    // beside the symbol -> id table.  (Nothing below throws past a thread: allocation failures are caught and reported.)
     U32 vtext, btext;
-    if (!decode_utf8_strict(vocab, vocab_len, vtext)) { err = "vocab file: invalid UTF-8"; return GZ_E_UTF8; }
-    if (!decode_utf8_strict(bpe, bpe_len, btext)) { err = "bpe file: invalid UTF-8"; return GZ_E_UTF8; }
-    universal_newlines(vtext);
-    universal_newlines(btext);
-
-    // ---- encoder (tokenize.py:31-37, :44-51) ------------------------------------------------------------
     OrderedDict enc;
-    {
-        size_t lines = 8;
-        for (char32_t c : vtext) lines += c == '\n';
-        enc.reserve(lines);
-    }
-    for (int i = 0; i < 5; ++i) enc.set(specials[i], i);
-    {
-        size_t i = 0, n = vtext.size();
-        while (i < n) {                                   // readlines(): split after every '\n', no empty tail
-            size_t j = i;
-            while (j < n && vtext[j] != '\n') ++j;
-            size_t a = i, b = j;                          // line without its '\n'
-            while (a < b && is_space(vtext[a])) ++a;      // .strip()
-            while (b > a && is_space(vtext[b - 1])) --b;
-            // idx = line.rfind(' '); word = line[:idx]   (idx == -1 -> drop the last character)
-            size_t cut;
-            size_t k = b;
-            while (k > a && vtext[k - 1] != ' ') --k;
-            if (k > a) cut = k - 1;                       // position of the last ' '
-            else cut = (b > a) ? b - 1 : a;               // no space: line[:-1]; empty line: ''
-            std::string word = to_utf8(vtext.data() + a, vtext.data() + cut);
-            // what follows the last space is ignored by the reference; when it is a number (the bundled vocab: the word's corpus
-            // count) it is kept as a placement HINT for the whole-word table (its most frequent words share a few lines)
-            uint64_t cnt = 0;
-            bool digits = k > a && cut + 1 < b;
-            for (size_t q = cut + 1; q < b && digits; ++q) {
-                if (vtext[q] < '0' || vtext[q] > '9' || cnt > (1ull << 56)) digits = false;
-                else cnt = cnt * 10 + (uint64_t)(vtext[q] - '0');
-            }
-            enc.set(word, (int32_t)enc.size(), digits ? cnt : 0);       // len(encoder) BEFORE the insertion
-            i = (j < n) ? j + 1 : j;
+    int rc_v = GZ_OK;
+    std::string err_v;
+    auto vocab_side = [&]() {
+      try {
+        if (!decode_utf8_strict(vocab, vocab_len, vtext)) { err_v = "vocab file: invalid UTF-8"; rc_v = GZ_E_UTF8; return; }
+        universal_newlines(vtext);
+        // ---- encoder (tokenize.py:31-37, :44-51) ------------------------------------------------------------
+        {
+            size_t lines = 8;
+            for (char32_t c : vtext) lines += c == '\n';
+            enc.reserve(lines);
         }
-    }
-    T.enc_words = enc.keys;
-    T.enc_ids = enc.vals;
-    T.enc_count = enc.aux;
-    for (int i = 0; i < 5; ++i) T.special_ids[i] = *enc.get(specials[i]);
-    const int32_t unk_id = T.special_ids[4];
+        for (int i = 0; i < 5; ++i) enc.set(specials[i], i);
+        {
+            size_t i = 0, n = vtext.size();
+            while (i < n) {                                   // readlines(): split after every '\n', no empty tail
+                size_t j = i;
+                while (j < n && vtext[j] != '\n') ++j;
+                size_t a = i, b = j;                          // line without its '\n'
+                while (a < b && is_space(vtext[a])) ++a;      // .strip()
+                while (b > a && is_space(vtext[b - 1])) --b;
+                // idx = line.rfind(' '); word = line[:idx]   (idx == -1 -> drop the last character)
+                size_t cut;
+                size_t k = b;
+                while (k > a && vtext[k - 1] != ' ') --k;
+                if (k > a) cut = k - 1;                       // position of the last ' '
+                else cut = (b > a) ? b - 1 : a;               // no space: line[:-1]; empty line: ''
+                std::string word = to_utf8(vtext.data() + a, vtext.data() + cut);
+                // what follows the last space is ignored by the reference; when it is a number (the bundled vocab: the word's corpus
+                // count) it is kept as a placement HINT for the whole-word table (its most frequent words share a few lines)
+                uint64_t cnt = 0;
+                bool digits = k > a && cut + 1 < b;
+                for (size_t q = cut + 1; q < b && digits; ++q) {
+                    if (vtext[q] < '0' || vtext[q] > '9' || cnt > (1ull << 56)) digits = false;
+                    else cnt = cnt * 10 + (uint64_t)(vtext[q] - '0');
+                }
+                enc.set(word, (int32_t)enc.size(), digits ? cnt : 0);       // len(encoder) BEFORE the insertion
+                i = (j < n) ? j + 1 : j;
+            }
+        }
+        T.enc_words = enc.keys;
+        T.enc_ids = enc.vals;
+        T.enc_count = enc.aux;
+        for (int i = 0; i < 5; ++i) T.special_ids[i] = *enc.get(specials[i]);
+      } catch (...) { err_v = "out of memory while reading the vocab file"; rc_v = GZ_E_NOMEM; }
+    };
+    std::thread vocab_thread(vocab_side);
+    struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } vocab_join{vocab_thread};      // (every return path joins)
+    // the reference reads the vocab file first (tokenize.py:44-51, then :53-57): its error wins over one of the merge side
+    auto fail_merge_side = [&](int rc, const char* what) { vocab_thread.join(); if (rc_v) { err = err_v; return rc_v; } err = what; return rc; };
+    if (!decode_utf8_strict(bpe, bpe_len, btext)) return fail_merge_side(GZ_E_UTF8, "bpe file: invalid UTF-8");
+    universal_newlines(btext);
 
     // ---- bpe_ranks (tokenize.py:53-57) --------------------------------------------------------------------
     OrderedDict ranks;                                    // key = fields joined by '\n'; aux = the number of fields
@@ -268,7 +280,7 @@ int gz_build_tables(const uint8_t* vocab, size_t vocab_len, const uint8_t* bpe, 
             i = j + 1;
         }
         rows.pop_back();
-        if (rows.size() > GZ_MAX_RANKS) { err = "bpe file: too many lines"; return GZ_E_LIMIT; }
+        if (rows.size() > GZ_MAX_RANKS) return fail_merge_side(GZ_E_LIMIT, "bpe file: too many lines");
         ranks.reserve(rows.size());
         for (size_t r = 0; r < rows.size(); ++r) {
             std::string key;
@@ -344,6 +356,40 @@ int gz_build_tables(const uint8_t* vocab, size_t vocab_len, const uint8_t* bpe, 
         T.merges[f.rank] = GzMergeInfo{ia, ib, im, 0};
         pairs.push_back({ia, ib, f.rank});
     }
+    // ---- pair -> rank, perfectly hashed: 8-byte entries, one load per probe ------------------------------------
+    int rc_p = GZ_OK;
+    auto pair_side = [&]() {
+      try {
+        std::vector<uint32_t> slot_of;
+        auto hashes = [](const void* ctx, size_t i, uint32_t k1, uint32_t k2, uint32_t* ha, uint32_t* hb) {
+            const Pair& p = (*static_cast<const std::vector<Pair>*>(ctx))[i];
+            *ha = gz_pair_ha(p.a, p.b, k1, k2); *hb = gz_pair_hb(p.a, p.b);
+        };
+        gz_ph_build(pairs.size(), hashes, &pairs, T.pair_ph, slot_of);
+        T.pair8.assign(T.pair_ph.slots, GzPair8{0xFFFFFFFFu, 0xFFFFFFFFu});
+        for (size_t i = 0; i < pairs.size(); ++i) {
+            const Pair& p = pairs[i];
+            const uint32_t merged = T.merges[p.rank].merged;
+            T.pair8[slot_of[i]] = GzPair8{p.a | (p.b << 20), (p.b >> 12) | (p.rank << 9) | (merged != p.rank ? GZ_PAIR8_ALIAS : 0u)};
+        }
+        // hot set: merges are learned most frequent first, so the smallest ranks are the pairs running text asks for most;
+        // direct-mapped by the top bits of ha, the smaller rank keeps a contested slot
+        T.pair_hot.assign(GZ_PAIR_HOT_SLOTS, GzPair8{0xFFFFFFFFu, 0xFFFFFFFFu});
+        std::vector<uint32_t> by_rank(pairs.size());
+        for (size_t i = 0; i < pairs.size(); ++i) by_rank[i] = (uint32_t)i;
+        std::sort(by_rank.begin(), by_rank.end(), [&](uint32_t x, uint32_t y) { return pairs[x].rank < pairs[y].rank; });
+        for (uint32_t i : by_rank) {
+            const Pair& p = pairs[i];
+            GzPair8& h = T.pair_hot[gz_pair_ha(p.a, p.b, T.pair_ph.k1, T.pair_ph.k2) >> GZ_PAIR_HOT_SHIFT];
+            if (h.lo == 0xFFFFFFFFu) h = T.pair8[slot_of[i]];
+        }
+      } catch (...) { rc_p = GZ_E_NOMEM; }
+    };
+    std::thread pair_thread(pair_side);                         // (reads pairs and T.merges, writes T.pair_*: nothing the code below touches)
+    Joiner pair_join{pair_thread};
+    vocab_thread.join();                                         // ---- the vocabulary is needed from here on
+    if (rc_v) { err = err_v; return rc_v; }
+    const int32_t unk_id = T.special_ids[4];
     // single-character forms the vocab knows: token "c" is the final piece of symbol c+"</w>", token "c@@" is
     // the non-final piece of symbol c
     for (const std::string& w : enc.keys) {
@@ -403,32 +449,8 @@ int gz_build_tables(const uint8_t* vocab, size_t vocab_len, const uint8_t* bpe, 
         }
     }
 
-    // ---- pair -> rank, perfectly hashed: 8-byte entries, one load per probe ------------------------------------
-    {
-        std::vector<uint32_t> slot_of;
-        auto hashes = [](const void* ctx, size_t i, uint32_t k1, uint32_t k2, uint32_t* ha, uint32_t* hb) {
-            const Pair& p = (*static_cast<const std::vector<Pair>*>(ctx))[i];
-            *ha = gz_pair_ha(p.a, p.b, k1, k2); *hb = gz_pair_hb(p.a, p.b);
-        };
-        gz_ph_build(pairs.size(), hashes, &pairs, T.pair_ph, slot_of);
-        T.pair8.assign(T.pair_ph.slots, GzPair8{0xFFFFFFFFu, 0xFFFFFFFFu});
-        for (size_t i = 0; i < pairs.size(); ++i) {
-            const Pair& p = pairs[i];
-            const uint32_t merged = T.merges[p.rank].merged;
-            T.pair8[slot_of[i]] = GzPair8{p.a | (p.b << 20), (p.b >> 12) | (p.rank << 9) | (merged != p.rank ? GZ_PAIR8_ALIAS : 0u)};
-        }
-        // hot set: merges are learned most frequent first, so the smallest ranks are the pairs running text asks for most;
-        // direct-mapped by the top bits of ha, the smaller rank keeps a contested slot
-        T.pair_hot.assign(GZ_PAIR_HOT_SLOTS, GzPair8{0xFFFFFFFFu, 0xFFFFFFFFu});
-        std::vector<uint32_t> by_rank(pairs.size());
-        for (size_t i = 0; i < pairs.size(); ++i) by_rank[i] = (uint32_t)i;
-        std::sort(by_rank.begin(), by_rank.end(), [&](uint32_t x, uint32_t y) { return pairs[x].rank < pairs[y].rank; });
-        for (uint32_t i : by_rank) {
-            const Pair& p = pairs[i];
-            GzPair8& h = T.pair_hot[gz_pair_ha(p.a, p.b, T.pair_ph.k1, T.pair_ph.k2) >> GZ_PAIR_HOT_SHIFT];
-            if (h.lo == 0xFFFFFFFFu) h = T.pair8[slot_of[i]];
-        }
-    }
+    pair_thread.join();
+    if (rc_p) { err = "out of memory while hashing the pair table"; return rc_p; }
     return GZ_OK;
 }
 
