@@ -98,7 +98,6 @@ struct gz_ctx {
         bool keep_words = false;
         int t_slot = 0;                // timing: the call's pair of events in the ring
         bool chained = false;          // enqueued behind a call that has not been synchronised (its scan flag is kept)
-        bool apart = false; int flip = 0;   // the row kernel on the rows stream; workspace slot of the call (GZ_ROWS_CUS)
         bool inputs_resident = false;  // the caller's device buffers are readable now (no copy of them is queued on the stream)
     } pend;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -119,14 +118,6 @@ struct gz_ctx {
     uint32_t lb_epoch = 0;               // call number of the chained scan (gz_split_kernel)   // [slot][text]
     hipStream_t stream2 = nullptr;       // sub-batches alternate between the two streams
     hipStream_t side = nullptr;          // the wide-word kernels of a text run here, beside the merge kernel
-    // GZ_ROWS_CUS=K (experiment, off by default): the row kernel of a dense single-text device call runs on a stream of its own that
-    // owns K compute units, the text side on the other 256 - K; consecutive calls alternate between the two workspace slots, so
-    // that the row kernel of call i runs beside the text side of call i + 1
-    hipStream_t rows_stream = nullptr;
-    hipEvent_t ev_text[2] = {nullptr, nullptr}, ev_rows[2] = {nullptr, nullptr};
-    bool rows_rec[2] = {false, false};
-    uint64_t apart_seq = 0;
-    bool rows_used = false;
     bool flags_lazy = false;       // the device flags of the pending chain have not been copied to h_flags yet (sync_locked does it)
     bool caller_buffers = false;   // set by the device entry points around encode_device_locked: text / offsets are the caller's
                                    // own device buffers (readable now), not staging copies queued on the stream
@@ -238,13 +229,6 @@ int enqueue(gz_ctx* c)
     hipStream_t s = c->stream;
     const GzDeviceTables* T = (const GzDeviceTables*)c->t_struct.p;
     if (c->x_used) HIPCHK(c, hipStreamWaitEvent(s, c->ev_x, 0));    // output buffers may still be read by an exchange step
-    if (c->rows_used) {
-        // row kernels of earlier calls may still run on the rows stream: a call of the same kind waits for the one that used ITS
-        // workspace slot (two calls back); any other call waits for all of them
-        if (p.apart) { if (c->rows_rec[p.flip]) HIPCHK(c, hipStreamWaitEvent(s, c->ev_rows[p.flip], 0)); }
-        else for (int i = 0; i < 2; ++i) if (c->rows_rec[i]) HIPCHK(c, hipStreamWaitEvent(s, c->ev_rows[i], 0));
-    }
-    if (p.apart && c->x_used) HIPCHK(c, hipStreamWaitEvent(c->rows_stream, c->ev_x, 0));
     const bool no_flags = p.small && !p.ragged;                 // (a dense one-launch call raises no flag)
     // [0] scan time-out, [1] capacity error, [3] a word needs the wide / long kernels.  Calls chained without a host
     // synchronisation keep [0]: it is only cleared when a chain starts, so a time-out in ANY call of the chain is still
@@ -273,19 +257,13 @@ int enqueue(gz_ctx* c)
     for (size_t k = 0; k < p.subs.size(); ++k) {
         hipStream_t sk = (k & 1) ? c->stream2 : s;
         const GzAsmArgs& S = p.subs[k];
-        const int e = (int)((k + (size_t)p.flip) & 1);
         for (int tx = 0; tx < S.n_texts; ++tx)
-            gz_launch_pipeline_text(T, c->dev, S.X[tx], S.n_docs, p.use_words, (int32_t*)c->w_flags.p + 3, sk, c->side, c->ev_sf0[e][tx], c->ev_sf[e][tx], c->ev_sj[e][tx],
-                                    p.inputs_resident ? c->ev_sb[e][tx] : nullptr);
-        if (p.apart) {
-            HIPCHK(c, hipEventRecord(c->ev_text[p.flip], s)); HIPCHK(c, hipStreamWaitEvent(c->rows_stream, c->ev_text[p.flip], 0));
-            gz_launch_assemble(T, S, c->rows_stream);
-            HIPCHK(c, hipEventRecord(c->ev_rows[p.flip], c->rows_stream));
-            c->rows_rec[p.flip] = true; c->rows_used = true;
-        } else gz_launch_assemble(T, S, sk);
+            gz_launch_pipeline_text(T, c->dev, S.X[tx], S.n_docs, p.use_words, (int32_t*)c->w_flags.p + 3, sk, c->side, c->ev_sf0[k & 1][tx], c->ev_sf[k & 1][tx], c->ev_sj[k & 1][tx],
+                                    p.inputs_resident ? c->ev_sb[k & 1][tx] : nullptr);
+        gz_launch_assemble(T, S, sk);
     }
     if (two) { HIPCHK(c, hipEventRecord(c->ev_join, c->stream2)); HIPCHK(c, hipStreamWaitEvent(s, c->ev_join, 0)); }
-    if (p.timing) { p.t_slot = (int)(c->ring_n % gz_ctx::RING); HIPCHK(c, hipEventRecord(c->ring[p.t_slot][1], p.apart ? c->rows_stream : s)); c->ring_n++; }
+    if (p.timing) { p.t_slot = (int)(c->ring_n % gz_ctx::RING); HIPCHK(c, hipEventRecord(c->ring[p.t_slot][1], s)); c->ring_n++; }
     if (p.ragged) {
         gz_launch_rowscan(p.F, (int64_t*)c->w_rowlen.p, s);
         gz_launch_finalize(c->dev, p.F, s);
@@ -296,7 +274,7 @@ int enqueue(gz_ctx* c)
     if (lazy_flags) c->flags_lazy = true;
     else if (!no_flags) { HIPCHK(c, hipMemcpyAsync(c->h_flags, c->w_flags.p, 8, hipMemcpyDeviceToHost, s)); c->flags_lazy = false; }
     else if (!p.chained) c->h_flags[0] = c->h_flags[1] = 0;
-    HIPCHK(c, hipEventRecord(c->ev_tok[c->enc_seq & 3], p.apart ? c->rows_stream : s));
+    HIPCHK(c, hipEventRecord(c->ev_tok[c->enc_seq & 3], s));
     c->enc_seq++;
     HIPCHK(c, hipGetLastError());
     return GZ_OK;
@@ -324,7 +302,6 @@ int sync_locked(gz_ctx* c)
         HIPCHK(c, hipMemcpyAsync(c->h_flags, c->w_flags.p, 8, hipMemcpyDeviceToHost, c->stream));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->rows_used) { HIPCHK(c, hipStreamSynchronize(c->rows_stream)); c->rows_used = false; c->rows_rec[0] = c->rows_rec[1] = false; }
     if (c->x_used) HIPCHK(c, hipStreamSynchronize(c->xstream));
     gz_ctx::Pending& p = c->pend;
     if (!p.active) return GZ_OK;
@@ -535,8 +512,6 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
             }
         }
     }
-    p.apart = c->rows_stream && nsub == 1 && dense && !is_pair && !p.keep_words && c->caller_buffers && h_text_off && max_len >= 4 && (max_len & 3) == 0 && max_len <= 1024;
-    p.flip = p.apart ? (int)(c->apart_seq++ & 1) : 0;
     p.subs.resize((size_t)nsub);
     for (int k = 0; k < nsub; ++k) {
         const int64_t lo = (int64_t)k * n_docs / nsub, hi = (int64_t)(k + 1) * n_docs / nsub;
@@ -549,7 +524,7 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
         S2.docs_per_wave = docs_per_wave;
         for (int tx = 0; tx < S2.n_texts; ++tx) {
             const int64_t* cut = tx ? cutB : cutA;
-            int rc2 = setup_text(c, c->tw[(k + p.flip) & 1][tx], c->w_tiny[(k + p.flip) & 7][tx], (tx ? pair : text) + cut[k], (tx ? pair_off : text_off) + lo,
+            int rc2 = setup_text(c, c->tw[k & 1][tx], c->w_tiny[k & 7][tx], (tx ? pair : text) + cut[k], (tx ? pair_off : text_off) + lo,
                                  cut[k + 1] - cut[k], S2.n_docs, c->stream, S2.X[tx]);
             if (rc2) return rc2;
         }
@@ -762,24 +737,7 @@ int gz_create(int device_id, gz_ctx** out)
     gz_ctx* c = new (std::nothrow) gz_ctx();
     if (!c) return fail(nullptr, GZ_E_NOMEM, "out of host memory");
     c->device = device_id;
-    const int rows_cus = getenv("GZ_ROWS_CUS") ? atoi(getenv("GZ_ROWS_CUS")) : 0;
-    bool masked = false;
-    if (rows_cus > 0 && rows_cus < prop.multiProcessorCount && prop.multiProcessorCount <= 512 && hipSetDevice(device_id) == hipSuccess) {
-        uint32_t m_text[16] = {0}, m_rows[16] = {0};
-        const int words = (prop.multiProcessorCount + 31) / 32;
-        // GZ_ROWS_MASK: 0 = the first K bits; 1 = K / 8 bits of every 32 (a slice of every XCD when a mask word is an XCD)
-        const int mode = getenv("GZ_ROWS_MASK") ? atoi(getenv("GZ_ROWS_MASK")) : 1;
-        for (int i = 0; i < prop.multiProcessorCount; ++i) {
-            const bool rows = mode == 0 ? i < rows_cus : (i % 32) < (rows_cus * 32 / prop.multiProcessorCount);
-            (rows ? m_rows : m_text)[i / 32] |= 1u << (i % 32);
-        }
-        masked = hipExtStreamCreateWithCUMask(&c->stream, (uint32_t)words, m_text) == hipSuccess &&
-                 hipExtStreamCreateWithCUMask(&c->rows_stream, (uint32_t)words, m_rows) == hipSuccess &&
-                 hipExtStreamCreateWithCUMask(&c->side, (uint32_t)words, m_text) == hipSuccess;
-        if (!masked) { delete c; return fail(nullptr, GZ_E_HIP, "GZ_ROWS_CUS: streams with a compute-unit mask could not be created"); }
-        for (int i = 0; i < 2; ++i) { hipEventCreateWithFlags(&c->ev_text[i], hipEventDisableTiming); hipEventCreateWithFlags(&c->ev_rows[i], hipEventDisableTiming); }
-    }
-    if (hipSetDevice(device_id) != hipSuccess || (!masked && hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) ||
+    if (hipSetDevice(device_id) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipHostMalloc((void**)&c->h_flags, 64, hipHostMallocDefault) != hipSuccess) {
         delete c;
         return fail(nullptr, GZ_E_HIP, "stream / pinned memory creation failed");
@@ -817,8 +775,6 @@ void gz_destroy(gz_ctx* c)
     if (c->ev_x) hipEventDestroy(c->ev_x);
     if (c->xstream) hipStreamDestroy(c->xstream);
     if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
-    if (c->rows_stream) { hipStreamSynchronize(c->rows_stream); hipStreamDestroy(c->rows_stream); }
-    for (int i = 0; i < 2; ++i) { if (c->ev_text[i]) hipEventDestroy(c->ev_text[i]); if (c->ev_rows[i]) hipEventDestroy(c->ev_rows[i]); }
     for (auto& a : c->ev_sf0) for (auto& e : a) if (e) hipEventDestroy(e);
     for (auto& a : c->ev_sb) for (auto& e : a) if (e) hipEventDestroy(e);
     for (auto& a : c->ev_sf) for (auto& e : a) if (e) hipEventDestroy(e);
