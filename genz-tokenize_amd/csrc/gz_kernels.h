@@ -124,6 +124,7 @@ struct GzPpFusedArgs {                          // the whole chain for short doc
     uint8_t* out; int64_t* out_len;             // the documents' slots of the chain's LAST buffer, their final lengths
     int32_t n_ops; int32_t ops[16];
     uint32_t* n_long;                           // += documents too long for this kernel (zeroed by the caller)
+    uint32_t* out_len32;                        // the same lengths as 32-bit words (0 for a document left to the chain): input of the chained scan
 };
 #ifndef GZ_PPF_CAP
 #define GZ_PPF_CAP 4096
@@ -134,3 +135,9 @@ void gz_launch_preprocess_fused(const GzPpFusedArgs& A, hipStream_t s);
 void gz_launch_scan64(const int64_t* len, int64_t n, int64_t* out_off /* n+1 */, hipStream_t s);
 void gz_launch_pp_pack(const uint8_t* in, const int64_t* in_off, const int64_t* len, int64_t n_docs, uint8_t* out, const int64_t* out_off,
                        hipStream_t s);
+// the tail of the pre-pass when gz_pp_fused_kernel did every document: exclusive scan of the 32-bit lengths IN PLACE (chained scan
+// over many workgroups, total at [n_docs]; lb / ctl / epoch as gz_scan32m_kernel wants them: ctl[1] = ticket counter, ctl[2] = time-out
+// flag, both zeroed by the caller), then the slots -> the packed text (out may be null; documents that end beyond capacity are not
+// written), four documents per wave, and out_off as 64-bit offsets
+void gz_launch_pp_tail(const uint8_t* slots, const int64_t* in_off, uint32_t* len32, int64_t n_docs, uint8_t* out, int64_t capacity, int64_t* out_off,
+                       unsigned long long* lb, uint32_t* ctl, uint32_t epoch, hipStream_t s);

@@ -586,7 +586,16 @@ void gz_launch_preprocess_fused(const GzPpFusedArgs& A, hipStream_t s)
 {
     static_assert(PPF_CAP == GZ_PP_FUSED_MAX_BYTES, "gz_kernels.h and gz_preproc.inc disagree");
     if (A.n_docs <= 0) return;
-    hipLaunchKernelGGL(gz_pp_fused_kernel, dim3((unsigned)((A.n_docs + PPF_WPB - 1) / PPF_WPB)), dim3(WAVE * PPF_WPB), 0, s, A);
+    hipLaunchKernelGGL(gz_pp_fused_kernel, dim3((unsigned)A.n_docs), dim3(WAVE), 0, s, A);
+}
+
+void gz_launch_pp_tail(const uint8_t* slots, const int64_t* in_off, uint32_t* len32, int64_t n_docs, uint8_t* out, int64_t capacity, int64_t* out_off,
+                       unsigned long long* lb, uint32_t* ctl, uint32_t epoch, hipStream_t s)
+{
+    if (n_docs <= 0) return;
+    hipLaunchKernelGGL(gz_scan32m_kernel, dim3((unsigned)((n_docs + SCH) / SCH)), dim3(256), 0, s, len32, n_docs, (uint32_t*)nullptr, lb, ctl + 1, epoch,
+                       reinterpret_cast<int32_t*>(ctl + 2));
+    hipLaunchKernelGGL(gz_pp_pack4_kernel, dim3((unsigned)((n_docs + 15) / 16)), dim3(WAVE * 4), 0, s, slots, in_off, (const uint32_t*)len32, n_docs, out, capacity, out_off);
 }
 
 void gz_launch_pp_pack(const uint8_t* in, const int64_t* in_off, const int64_t* len, int64_t n_docs, uint8_t* out, const int64_t* out_off, hipStream_t s)

@@ -1202,6 +1202,41 @@ def test_preprocess_fused_and_filter_by_filter_paths():
     assert " passed" in c.stdout and "failed" not in c.stdout
 
 
+def test_preprocess_device_size_query_and_small_capacity(tok, sampler):
+    """The pre-pass makes ONE synchronisation: the packed text is written before the host knows its size.  A capacity that is
+    too small must still be honoured on the device (nothing written behind it, GZ_E_CAPACITY afterwards), a call without an
+    output buffer returns the size and the offsets, and an empty batch returns [0]."""
+    from genz_tokenize import _native
+    ctx = tok._ctx
+    text, offs, L = corpus.config_corpus(2, n_docs=3000, seed=7, sampler=sampler)
+    offs = np.ascontiguousarray(offs, dtype=np.int64)
+    n, nbytes = len(offs) - 1, int(offs[-1])
+    d_text = ctx.alloc(len(text) + 64); ctx.h2d(d_text, text)
+    d_off = ctx.alloc(8 * (n + 1)); ctx.h2d(d_off, offs)
+    d_oo = ctx.alloc(8 * (n + 1))
+    ops = [3, 4]                                                       # punct, emoji: every document shrinks or stays
+    total = ctx.preprocess_device(ops, d_text, d_off, n, nbytes, 0, 0, d_oo)           # size query
+    oo = np.empty(n + 1, np.int64); ctx.d2h(oo, d_oo)
+    assert 0 < total < nbytes and oo[0] == 0 and oo[-1] == total and np.all(np.diff(oo) >= 0)
+    d_out = ctx.alloc(nbytes + 64)
+    assert ctx.preprocess_device(ops, d_text, d_off, n, nbytes, d_out, total, d_oo) == total   # exactly enough
+    full = np.empty(total, np.uint8); ctx.d2h(full, d_out)
+    cap = int(oo[n // 2]) + 5                                          # ends inside a document
+    guard = np.full(nbytes + 64, 0xA5, np.uint8); ctx.h2d(d_out, guard)
+    with pytest.raises(_native.GzError) as e:
+        ctx.preprocess_device(ops, d_text, d_off, n, nbytes, d_out, cap, d_oo)
+    assert e.value.code == _native.GZ_E_CAPACITY
+    got = np.empty(nbytes + 64, np.uint8); ctx.d2h(got, d_out)
+    assert np.all(got[cap:] == 0xA5)                                   # nothing behind the capacity
+    k = int(np.searchsorted(oo, cap, side="right")) - 1                # documents that end within it were written
+    assert np.array_equal(got[:oo[k]], full[:oo[k]])
+    assert ctx.preprocess_device(ops, d_text, d_off, 0, 0, d_out, 16, d_oo) == 0
+    z = np.full(1, -1, np.int64); ctx.d2h(z, d_oo)
+    assert z[0] == 0
+    for b in (d_text, d_off, d_oo, d_out):
+        ctx.free(b)
+
+
 def test_device_handoff_dlpack():
     """encode_to_device keeps the [N, L] outputs in HBM; torch.from_dlpack reads them zero-copy.  Runs in a child
     process because torch must initialise its GPU context BEFORE this library is loaded (both resolve the HIP runtime
