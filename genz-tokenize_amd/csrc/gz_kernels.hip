@@ -595,7 +595,7 @@ void gz_launch_pp_tail(const uint8_t* slots, const int64_t* in_off, uint32_t* le
     if (n_docs <= 0) return;
     hipLaunchKernelGGL(gz_scan32m_kernel, dim3((unsigned)((n_docs + SCH) / SCH)), dim3(256), 0, s, len32, n_docs, (uint32_t*)nullptr, lb, ctl + 1, epoch,
                        reinterpret_cast<int32_t*>(ctl + 2));
-    hipLaunchKernelGGL(gz_pp_pack4_kernel, dim3((unsigned)((n_docs + 15) / 16)), dim3(WAVE * 4), 0, s, slots, in_off, (const uint32_t*)len32, n_docs, out, capacity, out_off);
+    hipLaunchKernelGGL(gz_pp_pack4_kernel, dim3((unsigned)((n_docs + 4 * PACK_DOCS - 1) / (4 * PACK_DOCS))), dim3(WAVE * 4), 0, s, slots, in_off, (const uint32_t*)len32, n_docs, out, capacity, out_off);
 }
 
 void gz_launch_pp_pack(const uint8_t* in, const int64_t* in_off, const int64_t* len, int64_t n_docs, uint8_t* out, const int64_t* out_off, hipStream_t s)
