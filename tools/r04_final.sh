@@ -66,7 +66,7 @@ echo "(4)" >> $O/progress.txt
 trace cfg4 $R/tools/prof_cfg5.py 5 || exit 1
 echo "(5)" >> $O/progress.txt
 # (6)
-( cd $R && python3 tools/t_load.py > $O/table_load.txt 2>&1; python3 tools/small_bench.py > $O/small_calls.txt 2>&1 )
+( cd $R && python3 tools/t_load.py > $O/table_load.txt 2>&1; python3 tools/small_bench.py > $O/small_calls.txt 2>&1; tools/pp_trace.sh > $O/prepass_kernels.txt 2>&1 )
 echo "(6)" >> $O/progress.txt
 # (7) (the traffic files go where bench.py looks for them: this run's line then carries them)
 cp $O/pmc_traffic.json $R/profiles/r04_pmc_traffic.json; cp $O/pmc_traffic_shard.json $R/profiles/r04_pmc_traffic_shard.json; cp $O/pmc_traffic_cfg4.json $R/profiles/r04_pmc_traffic_cfg4.json
