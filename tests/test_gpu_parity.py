@@ -1166,6 +1166,23 @@ def test_preprocess_long_documents_vs_oracle():
             assert g == O.preprocess(d, ops), (ops, d[:80])
 
 
+def test_preprocess_character_classes_code_point_by_code_point():
+    """The punctuation + emoji pass takes its character classes (str.isspace, string.punctuation, the emoji ranges of
+    preprocess.py:51-70) from bit-mask lookups and decodes without a branch: EVERY code point up to U+3100, the emoji planes'
+    edges and the ends of the UTF-8 length classes, each between two letters (kept / deleted / turned into one space), against the
+    oracle -- alone, merged with remove_punctuations, and through the other filters."""
+    from genz_tokenize import preprocess as P
+    cps = [c for c in range(1, 0x3100) if not 0xD800 <= c <= 0xDFFF]
+    cps += [0xFFFF, 0x10000, 0x1F5FF, 0x1F600, 0x1F64F, 0x1F650, 0x1FAFF, 0x2FFFF, 0xE0001, 0x10FFFF, 0xFE0F, 0xFFFD, 0xD7FF, 0xE000]
+    docs = ["a" + chr(c) + "b" for c in cps]
+    docs += ["".join(chr(c) for c in cps[k:k + 50]) for k in range(0, len(cps), 50)]                # runs: carried states across classes
+    docs += ["x" * k + chr(c) + "y" for k in (61, 62, 63) for c in (0x20, 0x85, 0xA0, 0x1680, 0x2003, 0x3000, 0x2764, 0x1F600, 0x21)]   # across a 64-byte step
+    for ops in (["emoji"], ["punct", "emoji"], ["punct"], ["html", "unicode", "punct", "emoji", "url"]):
+        got = P.preprocess_batch(docs, ops)
+        for d, g in zip(docs, got):
+            assert g == O.preprocess(d, ops), (ops, [hex(ord(ch)) for ch in d[:6]], g)
+
+
 def test_preprocess_fused_and_filter_by_filter_paths():
     """Documents of at most 4 096 bytes run their whole filter chain in one kernel, on chip (gz_pp_fused_kernel, with filters
     skipped when a look at the bytes shows they cannot apply); longer ones go filter by filter through HBM.  Both against the
