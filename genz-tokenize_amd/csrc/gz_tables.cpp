@@ -259,10 +259,13 @@ int gz_build_tables(const uint8_t* vocab, size_t vocab_len, const uint8_t* bpe, 
         for (int i = 0; i < 5; ++i) T.special_ids[i] = *enc.get(specials[i]);
       } catch (...) { err_v = "out of memory while reading the vocab file"; rc_v = GZ_E_NOMEM; }
     };
-    std::thread vocab_thread(vocab_side);
+    // (a thread that cannot be started -- std::system_error -- is no reason to fail: the work is then done here, in line)
+    auto start = [](std::thread& t, auto& work) { try { t = std::thread(work); } catch (...) { work(); } };
+    std::thread vocab_thread;
+    start(vocab_thread, vocab_side);
     struct Joiner { std::thread& t; ~Joiner() { if (t.joinable()) t.join(); } } vocab_join{vocab_thread};      // (every return path joins)
     // the reference reads the vocab file first (tokenize.py:44-51, then :53-57): its error wins over one of the merge side
-    auto fail_merge_side = [&](int rc, const char* what) { vocab_thread.join(); if (rc_v) { err = err_v; return rc_v; } err = what; return rc; };
+    auto fail_merge_side = [&](int rc, const char* what) { if (vocab_thread.joinable()) vocab_thread.join(); if (rc_v) { err = err_v; return rc_v; } err = what; return rc; };
     if (!decode_utf8_strict(bpe, bpe_len, btext)) return fail_merge_side(GZ_E_UTF8, "bpe file: invalid UTF-8");
     universal_newlines(btext);
 
@@ -385,9 +388,10 @@ int gz_build_tables(const uint8_t* vocab, size_t vocab_len, const uint8_t* bpe, 
         }
       } catch (...) { rc_p = GZ_E_NOMEM; }
     };
-    std::thread pair_thread(pair_side);                         // (reads pairs and T.merges, writes T.pair_*: nothing the code below touches)
+    std::thread pair_thread;                                    // (reads pairs and T.merges, writes T.pair_*: nothing the code below touches)
+    start(pair_thread, pair_side);
     Joiner pair_join{pair_thread};
-    vocab_thread.join();                                         // ---- the vocabulary is needed from here on
+    if (vocab_thread.joinable()) vocab_thread.join();            // ---- the vocabulary is needed from here on
     if (rc_v) { err = err_v; return rc_v; }
     const int32_t unk_id = T.special_ids[4];
     // single-character forms the vocab knows: token "c" is the final piece of symbol c+"</w>", token "c@@" is
@@ -449,7 +453,7 @@ int gz_build_tables(const uint8_t* vocab, size_t vocab_len, const uint8_t* bpe, 
         }
     }
 
-    pair_thread.join();
+    if (pair_thread.joinable()) pair_thread.join();
     if (rc_p) { err = "out of memory while hashing the pair table"; return rc_p; }
     return GZ_OK;
 }
