@@ -190,3 +190,24 @@ def test_host_builder_under_sanitizers():
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
         assert "asan child ok" in r.stdout
         assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
+
+
+def test_host_builder_threads_under_tsan(tmp_path):
+    """The builder runs the vocab side and the pair table's perfect hash on helper threads: the same sources under
+    g++ -fsanitize=thread, over the bundled tables (three builds) and over a vocab file that is not UTF-8 (the helper thread's error
+    must come back as the call's).  Any report fails the test."""
+    import os
+    import subprocess
+    from conftest import ROOT, DATA
+    csrc = os.path.join(ROOT, "genz-tokenize_amd", "csrc")
+    exe = str(tmp_path / "host_tsan")
+    c = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-DGZ_HOST_ONLY", "-I", csrc, "-I", os.path.join(ROOT, "include"),
+                        os.path.join(ROOT, "tests", "native", "host_tsan_main.cpp"), os.path.join(csrc, "gz_tables.cpp"), "-o", exe, "-lpthread"],
+                       capture_output=True, text=True, timeout=600)
+    if c.returncode != 0 and "tsan" in (c.stderr or "").lower() and "cannot find" in c.stderr:
+        pytest.skip("libtsan is not installed")
+    assert c.returncode == 0, c.stderr[-3000:]
+    r = subprocess.run([exe, os.path.join(DATA, "vocab.txt"), os.path.join(DATA, "bpe.codes")], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1:exitcode=66"))
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-4000:]
+    assert "tsan driver ok" in r.stdout and "ThreadSanitizer" not in r.stderr
