@@ -115,7 +115,7 @@ struct gz_ctx {
     DBuf t_pair8, t_pair_disp, t_words0p, t_word0_disp;      // the perfectly hashed tables (gz_common.h)
     DBuf t_pair_hot, t_word_hot;                             // hot sets the merge / word kernels stage in LDS
     struct TextWs { DBuf brk, st, en, blkcnt, docw0, wtok, waux, mtok, mlist, blkmiss, tilecnt, wlist, grpblk, lookback, mq; } tw[2][2];
-    uint32_t lb_epoch = 0;               // call number of the chained scan (gz_split_kernel)   // [slot][text]
+    uint32_t lb_epoch = 0;               // call number of the chained scans (gz_scan32m_kernel)   // [slot][text]
     hipStream_t stream2 = nullptr;       // sub-batches alternate between the two streams
     hipStream_t side = nullptr;          // the wide-word kernels of a text run here, beside the merge kernel
     bool flags_lazy = false;       // the device flags of the pending chain have not been copied to h_flags yet (sync_locked does it)
@@ -317,7 +317,7 @@ int sync_locked(gz_ctx* c)
         }
     }
     p.active = false;
-    if (c->h_flags[0]) return fail(c, GZ_E_HIP, "internal: a chained scan (gz_scan32m_kernel / gz_split_kernel look-back) timed out");
+    if (c->h_flags[0]) return fail(c, GZ_E_HIP, "internal: a chained scan (gz_scan32m_kernel look-back) timed out");
     if (c->h_flags[1]) return fail(c, GZ_E_CAPACITY, "ragged output larger than capacity");
     return GZ_OK;
 }
@@ -372,7 +372,7 @@ int setup_text(gz_ctx* c, gz_ctx::TextWs& W, DBuf& tiny, const uint8_t* tb, cons
     X.blklong = (uint32_t*)W.wlist.p; X.ctl = X.blklong + nbr; X.wlist = X.ctl + 64;     // (ONE memset clears the flags, the control words and the list's count)
     X.mq = (uint4*)W.mq.p;
     X.lookback = (uint64_t*)W.lookback.p;
-    // call numbers of the chained scans of this text: X.epoch (gz_split_kernel), + 1 and + 2 (gz_scan32m_kernel); they are
+    // call numbers of the chained scans of this text: X.epoch + 1 and + 2 (gz_scan32m_kernel; X.epoch itself is unused); they are
     // 1, 2, 3 mod 4, so never 0 in their low 30 bits (0 is what a fresh allocation may hold)
     c->lb_epoch += 4;
     if ((c->lb_epoch & 0x3FFFFFFFu) < 4u) {                      // the 30-bit call number wrapped: words of 2^28 calls ago would look current
