@@ -49,7 +49,7 @@ struct GzTextBufs {              // one text (A or B) of a batch and its per-cal
     uint4* mlist;                // [words] the misses of block b, compact, at mlist[blkcnt[b] ...]: {word index, byte offset, pending record, 0}
     uint32_t* blkmiss;           // [nblk+1] number of misses per block; scanned in place before the merge pre-pass ([nblk] = total)
     uint32_t* grpblk;            // [words/64 + 2] block that holds miss number 64 g (written by the scan)
-    uint32_t* tcnt;              // [words/1024 + 2] records of every 1 024-miss tile of mq that the merge kernel takes (gz_mpre_kernel)
+    uint32_t* tcnt;              // [words/2048 + 2] per 2 048-miss tile of mq: records the merge kernel takes | its chunks of 64 with a word of > 8 symbols << 16 (gz_mpre_kernel)
     int64_t wmax;                // upper bound of the number of words (sizes of the per-word arrays)
     uint32_t* ctl;               // [64] zeroed per call: [0] words for gz_long_kernel, [1] unused, [2] [3] ticket counters of the
                                  // chained scans, [4] cursor of the compact token area; wlist == ctl + 64

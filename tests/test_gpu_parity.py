@@ -323,19 +323,22 @@ def test_perfect_hash_overflow_buckets_on_the_gpu():
     assert " passed" in r.stdout and "failed" not in r.stdout
 
 
-@pytest.mark.parametrize("switches", [{"GZ_SIDE": "0", "GZ_BRK_SIDE": "0"}, {"GZ_ASSEMBLE": "2"}, {"GZ_ASSEMBLE": "1"}],
-                         ids=["one_stream", "lds_row_kernel", "scatter_row_kernel"])
+@pytest.mark.parametrize("switches", [{"GZ_SIDE": "0", "GZ_BRK_SIDE": "0"}, {"GZ_ASSEMBLE": "2"}, {"GZ_ASSEMBLE": "1"},
+                                      {"GZ_M2_SPLIT_MIN": "1", "GZ_M2_SPLIT_ALWAYS": "1"}],
+                         ids=["one_stream", "lds_row_kernel", "scatter_row_kernel", "two_merge_instances"])
 def test_alternative_kernels_stay_exact(switches):
     """Schedules and kernels the library keeps beside the default ones: everything on one stream (GZ_SIDE=0 / GZ_BRK_SIDE=0), and
     the pair-mode / ragged row writers run on dense single texts (GZ_ASSEMBLE=2: whole rows through LDS, the pair-mode kernel; 1:
-    the scatter kernel of the ragged layouts).  Each runs the golden batches,
-    the 20 k-document digests, the noisy corpora and the long words in a child process, small batches through the pipeline."""
+    the scatter kernel of the ragged layouts); the merge kernel's two instances (words of up to 8 / up to 16 symbols, gz_hot.inc)
+    sharing EVERY batch, however small and with the whole-word tables on -- by default they only do when the tables are off and
+    the misses are many.  Each runs the golden batches, the 20 k-document digests, the noisy corpora, bytes that are not UTF-8
+    and the long words in a child process, small batches through the pipeline."""
     import subprocess
     import sys
     env = dict(os.environ, GZ_SMALL="0", **switches)
     here = os.path.abspath(__file__)
     r = subprocess.run([sys.executable, "-m", "pytest", here, "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider", "-k",
-                        "g1_cases or g3_random_batched or cfg3_20k or noisy_corpus or long_and_huge or extreme_batch"],
+                        "g1_cases or g3_random_batched or cfg3_20k or noisy_corpus or long_and_huge or extreme_batch or not_utf8"],
                        env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
