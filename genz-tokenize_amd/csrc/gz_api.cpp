@@ -601,6 +601,7 @@ static int build_word_table(gz_ctx* c, WordImages& W)
     phase("GPU merge path over the candidates");
     std::vector<GzWordSlot2> found2;                         // 17..32 bytes: the long-key table (probed once per miss)
     std::vector<GzWordSlot1> found1;                         // <= 16 bytes: perfectly hashed, one probe per word
+    std::vector<uint32_t> found1_sym;                        // ... and the symbol (word + "</w>") each of them is
     for (int64_t i = 0; i < n; ++i) {
         if (row[i + 1] - row[i] != 3) continue;
         const int32_t id = ids[row[i] + 1];
@@ -613,6 +614,7 @@ static int build_word_table(gz_ctx* c, WordImages& W)
             e1.meta = len | ((uint32_t)id << 5);
             std::memcpy(e1.k, key, 12); std::memcpy(&e1.k3, key + 12, 4);
             found1.push_back(e1);
+            found1_sym.push_back(which[(size_t)i]);
         } else {
             GzWordSlot2 e{{0, 0, 0, 0}, len, id, {0, 0, 0, 0, 0, 0}};
             std::memcpy(e.k, key, 32);
@@ -634,19 +636,30 @@ static int build_word_table(gz_ctx* c, WordImages& W)
         std::vector<uint8_t> hotf;
         std::vector<std::pair<uint64_t, uint32_t>> by_weight;       // (weight, index into found1), heaviest first
         {
-            // a recorded word's id IS its vocab entry's id (the GPU looked the whole word up): the weights go by id
+            // a recorded word's id IS its vocab entry's id (the GPU looked the whole word up): the weights go by id.  The counts a vocab
+            // file carries are believed when the file is sorted by them (as the tool that writes such files leaves it); a file without
+            // counts, or with counts in no order, says nothing about frequency -- the MERGES do: they were learned most frequent
+            // first, and a whole word's symbol is numbered by the merge that completed it (symbols no merge produces -- single
+            // characters -- count as most frequent)
             bool any = false;
-            for (uint64_t h : H.enc_count) if (h) { any = true; break; }
+            size_t rising = 0;
+            for (size_t i = 0; i < H.enc_count.size(); ++i) { any |= H.enc_count[i] != 0; rising += i > 5 && H.enc_count[i] > H.enc_count[i - 1]; }
+            bool by_count = any && rising * 100 <= H.enc_count.size();
+            if (const char* e = getenv("GZ_WORD_WEIGHTS")) by_count = any && e[0] == 'c';       // (A/B: "counts" / "merges")
             std::vector<uint64_t> weight_of_id(H.enc_words.size(), 0);          // (ids are sizes of the dict at insertion: < its size)
-            for (size_t i = 0; i < H.enc_words.size(); ++i) {
-                const int32_t id = H.enc_ids[i];
-                if (id >= 0 && (size_t)id < weight_of_id.size()) weight_of_id[(size_t)id] = any ? H.enc_count[i] : (uint64_t)(H.enc_words.size() - i);
-            }
+            if (by_count)
+                for (size_t i = 0; i < H.enc_words.size(); ++i) {
+                    const int32_t id = H.enc_ids[i];
+                    if (id >= 0 && (size_t)id < weight_of_id.size()) weight_of_id[(size_t)id] = H.enc_count[i];
+                }
             const uint32_t unk = (uint32_t)H.special_ids[4];                    // (a word the vocab does not hold: no weight)
+            const uint64_t n_lines = H.merges.size();
             std::vector<std::pair<uint64_t, uint32_t>> order(found1.size());
             for (size_t i = 0; i < found1.size(); ++i) {
                 const uint32_t id = found1[i].meta >> 5;
-                order[i] = {(id == unk || id >= weight_of_id.size()) ? 0 : weight_of_id[id], (uint32_t)i};
+                uint64_t w = 0;
+                if (id != unk) w = by_count ? (id < weight_of_id.size() ? weight_of_id[id] : 0) : (found1_sym[i] < n_lines ? n_lines - found1_sym[i] : n_lines + 1);
+                order[i] = {w, (uint32_t)i};
             }
             std::sort(order.begin(), order.end(), [](const std::pair<uint64_t, uint32_t>& x, const std::pair<uint64_t, uint32_t>& y) { return x.first != y.first ? x.first > y.first : x.second < y.second; });
             if (hot_slots) {
