@@ -1257,6 +1257,32 @@ def test_preprocess_device_size_query_and_small_capacity(tok, sampler):
         ctx.free(b)
 
 
+@pytest.mark.parametrize("n", [16383, 16384, 16385, 18432, 18433, 40000])
+def test_row_offsets_of_large_ragged_batches(tok, n):
+    """Ragged layouts, batch decode and the pre-pass's general tail get their offsets from a 64-bit scan that runs on many
+    workgroups from 16 384 rows on (gz_scan64_*: block totals travel in the next block's first slot): sizes around the switch
+    and around its 2 048-row blocks, rows of seven different lengths (empty documents among them), offsets and contents against
+    the oracle; the same rows back through batch decode."""
+    kinds = ["", "a", "vi\u1ec7t nam", "xin ch\u00e0o c\u00e1c b\u1ea1n", "h\u1ecdc sinh gi\u1ecfi", "zzqqx", "c\u00f4ng_ngh\u1ec7 th\u00f4ng_tin 2024"]
+    docs = [kinds[(i * 7 + i // 3) % len(kinds)] for i in range(n)]
+    raw = [d.encode("utf-8") for d in docs]
+    offs = np.zeros(n + 1, np.int64); np.cumsum([len(b) for b in raw], out=offs[1:])
+    text = np.frombuffer(b"".join(raw), dtype=np.uint8)
+    got = tok.encode_packed(text, offs, max_len=None)
+    ro = np.asarray(got["row_off"], dtype=np.int64)
+    ids = np.asarray(got["input_ids"]).reshape(-1)
+    single = {k: tok(k)["input_ids"] for k in kinds}                  # (the single-call path is checked against the reference elsewhere)
+    lens = np.array([len(single[d]) for d in docs], dtype=np.int64)
+    assert ro[0] == 0 and np.array_equal(np.diff(ro), lens)
+    assert ro[-1] == len(ids)
+    for i in list(range(0, n, 997)) + [2047, 2048, 2049, 16383, n - 1]:
+        if i < n:
+            assert ids[ro[i]:ro[i + 1]].tolist() == single[docs[i]], i
+    back = tok.decode_batch([ids[ro[i]:ro[i + 1]].tolist() for i in range(n)])
+    ref = {k: tok.decode(single[k]) for k in kinds}
+    assert back == [ref[d] for d in docs]
+
+
 def test_device_handoff_dlpack():
     """encode_to_device keeps the [N, L] outputs in HBM; torch.from_dlpack reads them zero-copy.  Runs in a child
     process because torch must initialise its GPU context BEFORE this library is loaded (both resolve the HIP runtime
