@@ -295,6 +295,10 @@ int x_end(gz_ctx* c)
     return GZ_OK;
 }
 
+#ifdef GZ_DIAG
+extern "C" int gz_diag_check(unsigned int* out8, int clear);      // gz_hot.inc: the record of the kernels' index assertions
+#endif
+
 int sync_locked(gz_ctx* c)
 {
     if (c->flags_lazy) {                                         // the flags of a chain of dense calls: copied once, now
@@ -303,6 +307,17 @@ int sync_locked(gz_ctx* c)
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (c->x_used) HIPCHK(c, hipStreamSynchronize(c->xstream));
+#ifdef GZ_DIAG
+    {
+        // diagnostic build: an index the kernels took out of memory did not fit the array it was meant for (the access was skipped)
+        unsigned int e[8] = {0};
+        if (gz_diag_check(e, 1) == 0 && e[0] != 0u) {
+            c->pend.active = false;
+            return fail(c, GZ_E_HIP, "diagnostic build: index check %u failed: index %llu, bound %u, workgroup %u (%u failures in all)", e[0],
+                        (unsigned long long)e[1] | ((unsigned long long)e[2] << 32), e[3], e[5], e[4]);
+        }
+    }
+#endif
     gz_ctx::Pending& p = c->pend;
     if (!p.active) return GZ_OK;
     if (p.timing) {
@@ -328,7 +343,7 @@ int setup_text(gz_ctx* c, gz_ctx::TextWs& W, DBuf& tiny, const uint8_t* tb, cons
                hipStream_t s, GzTextBufs& X)
 {
     if (Bt < 0) return fail(c, GZ_E_INVALID, "offsets are not non-decreasing");
-    if (Bt >= (int64_t)0xFFFF0000ll) return fail(c, GZ_E_LIMIT, "a batch of 4 GiB or more of text must be split");
+    if (Bt >= GZ_TEXT_BYTES_LIMIT) return fail(c, GZ_E_LIMIT, "a batch of 4 GiB or more of text must be split");
     X.tb = tb;
     if (Bt > 0 && Bt < 16) {
         // the kernels read the 16 bytes that END at the last byte of the text (load16 / load4_tail move a load
@@ -364,6 +379,18 @@ int setup_text(gz_ctx* c, gz_ctx::TextWs& W, DBuf& tiny, const uint8_t* tb, cons
         (rc2 = ensure(c, W.mq, (size_t)wmax * 16)) ||
         (rc2 = ensure(c, W.lookback, (size_t)(X.nblk / 4 + 4) * 8, /* zero a new allocation */ true)))
         return rc2;
+#ifdef GZ_DIAG
+    {
+        // GZ_DIAG_POISON=1 (diagnostic build): the whole per-call workspace is filled with 0xFF before every call, so that a kernel
+        // that consumes a word nobody wrote in THIS call reads an impossible index or a pending record every time, not just when the
+        // allocation happens to hold one (run with GZ_BRK_SIDE=0: the start bits are then cleared on this stream, behind the fill).
+        // The chained scans' words are left alone: they are validated by their call number.
+        static const bool poison = getenv("GZ_DIAG_POISON") && atoi(getenv("GZ_DIAG_POISON")) != 0;
+        if (poison)
+            for (DBuf* b : {&W.brk, &W.st, &W.en, &W.blkcnt, &W.docw0, &W.wtok, &W.waux, &W.mtok, &W.mlist, &W.grpblk, &W.blkmiss, &W.tilecnt, &W.wlist, &W.mq})
+                HIPCHK(c, hipMemsetAsync(b->p, 0xFF, b->cap, s));
+    }
+#endif
     X.brk = (uint16_t*)W.brk.p; X.st = (uint16_t*)W.st.p; X.en = (uint16_t*)W.en.p;
     X.blkcnt = (uint32_t*)W.blkcnt.p; X.docw0 = (uint32_t*)W.docw0.p;
     X.wtok = (uint32_t*)W.wtok.p; X.waux = (uint32_t*)W.waux.p; X.mtok = (int32_t*)W.mtok.p;
@@ -1621,7 +1648,11 @@ int preprocess_device_locked(gz_ctx* c, const int32_t* ops, int32_t n_ops, const
     const uint8_t* in = text_dev;
     const int64_t* in_len = nullptr;
     // documents of at most 4 KiB: the whole chain in one kernel, on chip (GZ_PP_FUSED=0: filter by filter like the long ones)
-    static const int fused = getenv("GZ_PP_FUSED") ? atoi(getenv("GZ_PP_FUSED")) : 1;
+    // (the fused kernel's tail -- lengths, their scan, the pack kernel's offsets, the total -- is 32-bit: filters never grow a
+    // document, so it is exact while the INPUT stays under 4 GiB; a larger input takes the filter-by-filter chain with its 64-bit
+    // scan and pack kernels)
+    static const int fused_env = getenv("GZ_PP_FUSED") ? atoi(getenv("GZ_PP_FUSED")) : 1;
+    const bool fused = fused_env != 0 && gz_pp_tail_is_32bit(in_bytes);
     if (fused && n_docs > 0) {
         GzPpFusedArgs F{};
         F.in = text_dev; F.in_off = off_dev; F.n_docs = n_docs;

@@ -27,6 +27,14 @@ constexpr uint32_t GZ_NO_SYMBOL   = 0xFFFFFFFFu;      // table entry: code point
 constexpr uint32_t GZ_RANK_NONE   = 0xFFFFFFFFu;      // "pair is not in bpe_ranks" (the float('inf') of tokenize.py:71)
 constexpr uint32_t GZ_PAIR_EMPTY  = 0xFFFFFFFFu;      // `left` of an empty pair slot
 
+// Byte counts the 32-bit paths take (gz_limit, include/genz_tokenize.h).  One text of an encode call: positions, word starts and
+// token places are 32-bit on the device (GZ_E_LIMIT from this size on: split the batch).  The text pre-pass has no such limit of
+// its own: up to this many INPUT bytes it scans its output lengths in 32 bits (filters never grow a document, so the output
+// offsets and their total fit too); from this size on it takes the 64-bit scan and pack kernels.
+constexpr int64_t GZ_TEXT_BYTES_LIMIT = 0xFFFF0000ll;
+constexpr int64_t GZ_PP_TAIL32_LIMIT = 0xFFFF0000ll;
+inline bool gz_pp_tail_is_32bit(int64_t in_bytes) { return in_bytes >= 0 && in_bytes < GZ_PP_TAIL32_LIMIT; }
+
 GZ_HD uint32_t gz_cp_hash(uint32_t cp)
 {
     uint32_t h = cp * 0x9E3779B1u;

@@ -58,7 +58,6 @@ int gz_host_tables_array(gz_host_tables* t, int which, const void** data, int64_
         case 3: *data = H.bmp.data();      *count = (int64_t)H.bmp.size(); break;
         case 4: *data = H.astral.data();   *count = (int64_t)H.astral.size(); break;
         case 5: *data = H.special_ids;     *count = 5; break;
-        // (0 was the linear-probing pair table of rounds 1-3: gone)
         // the pair table, perfectly hashed: entries, displacement array, {nbuckets, bshift, sshift, slots, k1, k2, keys in
         // overflow buckets}, hot set
         case 6: *data = H.pair8.data();    *count = (int64_t)H.pair8.size(); break;
@@ -71,9 +70,18 @@ int gz_host_tables_array(gz_host_tables* t, int which, const void** data, int64_
             *data = ph; *count = 7; break;
         }
         case 9: *data = H.pair_hot.data(); *count = (int64_t)H.pair_hot.size(); break;
-        default: return GZ_E_INVALID;
+        default: *data = nullptr; *count = 0; return GZ_E_INVALID;      // (0 included: the linear-probing pair table is gone)
     }
     return GZ_OK;
+}
+
+int64_t gz_limit(int which)
+{
+    switch (which) {
+        case 0: return GZ_TEXT_BYTES_LIMIT;
+        case 1: return GZ_PP_TAIL32_LIMIT;
+        default: return -1;
+    }
 }
 
 int gz_host_tables_vocab_entry(gz_host_tables* t, int64_t i, const uint8_t** utf8, int32_t* len, int32_t* id)

@@ -22,6 +22,26 @@ constexpr int GMAX = GZ_MAX_DOCS_PER_WAVE;   // documents per wave of the assemb
 
 __device__ __forceinline__ int lane_id() { return threadIdx.x & (WAVE - 1); }
 
+// Index assertions of the diagnostic build (-DGZ_DIAG): every scattered access of the pipeline whose index comes out of memory is
+// checked against the size of the array it goes into; a failed check is RECORDED (the first one: its code, the index, the bound,
+// the workgroup; and the number of failures) and the access is skipped -- the host reads the record when it synchronises
+// (gz_diag_check, sync_locked) and fails the call.  In the product build GZ_CHK is the constant `true` and compiles to nothing.
+// Codes: 1xx word kernel, 2xx merge pre-pass, 3xx merge kernel, 4xx wide / long kernels, 5xx row kernels, 6xx docw0.
+#ifdef GZ_DIAG
+__device__ unsigned int gz_diag_err[8];
+__device__ __noinline__ bool gz_chk_fail(unsigned code, unsigned long long v, unsigned long long bound)
+{
+    if (atomicCAS(&gz_diag_err[0], 0u, code) == 0u) {
+        gz_diag_err[1] = (unsigned)v; gz_diag_err[2] = (unsigned)(v >> 32); gz_diag_err[3] = (unsigned)bound; gz_diag_err[5] = blockIdx.x;
+    }
+    atomicAdd(&gz_diag_err[4], 1u);
+    return false;
+}
+#define GZ_CHK(code, v, bound) (((unsigned long long)(v) < (unsigned long long)(bound)) ? true : gz_chk_fail((code), (unsigned long long)(v), (unsigned long long)(bound)))
+#else
+#define GZ_CHK(code, v, bound) true
+#endif
+
 // streaming (write-once) 16-byte store that does not displace the tables from L2
 __device__ __forceinline__ void nt_store4(int32_t* p, int32_t a, int32_t b, int32_t c, int32_t d)
 {

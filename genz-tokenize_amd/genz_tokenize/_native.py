@@ -29,7 +29,7 @@ SYMBOLS = [
     "gz_timing", "gz_timing_history", "gz_decoder_snapshot", "gz_decode_batch", "gz_decode_batch_device", "gz_preprocess_batch",
     "gz_preprocess_batch_device", "gz_block_create", "gz_block_release", "gz_block_dlpack", "gz_dlpack_capsule_destructor", "gz_exchange_select", "gz_comm_unique_id", "gz_comm_init", "gz_gather_rows", "gz_compact_rows", "gz_expand_rows", "gz_compact_rows16", "gz_expand_rows16", "gz_compact_block", "gz_expand_block",
     "gz_host_tables_create", "gz_host_tables_destroy", "gz_host_tables_array", "gz_host_tables_vocab_entry",
-    "gz_host_tables_merge_entry", "gz_host_tables_symbol",
+    "gz_host_tables_merge_entry", "gz_host_tables_symbol", "gz_limit",
 ]
 
 _lib = None
@@ -108,8 +108,11 @@ def load_library():
             continue                                     # (an older build loaded for an A/B run: entry points it lacks stay unbound)
         fn = getattr(L, name)
         if name not in ("gz_destroy", "gz_last_error", "gz_bpe_word", "gz_host_tables_destroy", "gz_block_release", "gz_block_dlpack",
-                        "gz_dlpack_capsule_destructor"):
+                        "gz_dlpack_capsule_destructor", "gz_limit"):
             fn.restype = C.c_int
+    if hasattr(L, "gz_limit"):
+        L.gz_limit.argtypes = [C.c_int]
+        L.gz_limit.restype = i64
     _lib = L
     return L
 

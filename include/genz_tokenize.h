@@ -191,7 +191,7 @@ int  gz_timing(gz_ctx *ctx, double out_ms[4]);
 int  gz_timing_history(gz_ctx *ctx, double *out_ms, int32_t max, int32_t *n_out);
 
 /* Offline / diagnostic table build on the HOST only (no GPU needed): the same builder gz_load_tables runs, with
- * the integer tables it would upload exposed read-only.  `which`: 0 pair hash (uint32 x4 [slots]: left, right, merged symbol, rank; left = 0xFFFFFFFF: empty slot), 1 merges
+ * the integer tables it would upload exposed read-only.  `which` (0 is retired -- the linear-probing pair table of rounds 1-3 -- and answers GZ_E_INVALID like any unknown value, with *data = NULL and *count = 0): 1 merges
  * (uint32 x4 [n_lines]: left,right,merged,0), 2 symbol ids (int32 x2 [n_symbols]: non-final, final), 3 BMP code
  * point table (uint32 x2 [65536]: plain, final), 4 astral table (uint32 x4 [slots]: cp,plain,final,0; may be
  * empty), 5 special ids (int32 [5]); the perfectly hashed pair table of the big pipeline's merge kernel: 6 entries (uint32 x2
@@ -207,6 +207,12 @@ int  gz_host_tables_array(gz_host_tables *t, int which, const void **data, int64
 int  gz_host_tables_vocab_entry(gz_host_tables *t, int64_t i, const uint8_t **utf8, int32_t *len, int32_t *id);
 int  gz_host_tables_merge_entry(gz_host_tables *t, int64_t i, const uint8_t **utf8, int32_t *len, int32_t *n_fields, int32_t *rank);
 int  gz_host_tables_symbol(gz_host_tables *t, int32_t symbol, const uint8_t **utf8, int32_t *len);
+
+/* Byte counts the library's 32-bit device paths take (no context, no GPU needed).  which = 0: bytes of ONE text (text, or pair
+ * text) of an encode call from which the call answers GZ_E_LIMIT -- split the batch; 1: input bytes from which the text pre-pass
+ * (gz_preprocess_batch[_device], which has no size limit of its own) leaves its 32-bit length scan for the 64-bit one.  Both are
+ * below 2^32.  Unknown `which`: -1. */
+int64_t gz_limit(int which);
 
 /* ---- batch decode ------------------------------------------------------------------------
  * gz_decoder_snapshot: build the id -> word map from the tables loaded so far, the way the reference builds

@@ -28,6 +28,30 @@ def test_library_exports_every_declared_symbol():
     assert lib.gz_version() == 0x010000
 
 
+def test_limits_of_the_32_bit_paths():
+    """gz_limit: one text of an encode call is refused from 0xFFFF0000 bytes on (32-bit positions on the device); the text
+    pre-pass switches from its 32-bit length scan to the 64-bit one at an INPUT size below 2^32 (filters never grow a document, so
+    under that size no output offset and no total can wrap) -- round-4 advice: the 32-bit tail used to be taken at any size."""
+    native = pytest.importorskip("genz_tokenize._native")
+    lib = native.load_library()
+    enc, pp = lib.gz_limit(0), lib.gz_limit(1)
+    assert 0 < enc < 2**32 and 0 < pp < 2**32
+    assert pp <= 2**32 - 65536                      # slack for the kernels' 16-byte accesses behind the last document
+    assert lib.gz_limit(2) == -1 and lib.gz_limit(-1) == -1
+
+
+def test_retired_host_table_answers_invalid_and_clears_its_outputs():
+    native = pytest.importorskip("genz_tokenize._native")
+    ht = native.HostTables(b"a 1\nb 1\n", b"#version: 0.2\na b\n")
+    p, n = ctypes.c_void_p(123), ctypes.c_int64(456)
+    for which in (0, 10, -1):
+        p.value, n.value = 123, 456
+        assert ht.lib.gz_host_tables_array(ht.handle, which, ctypes.byref(p), ctypes.byref(n)) == native.GZ_E_INVALID
+        assert not p.value and n.value == 0
+    assert len(ht.array(1)) == 2
+    ht.close()
+
+
 def test_no_gpu_means_loud_failure_not_fallback():
     """Without a usable device the drop-in must raise, never compute on the CPU."""
     native = pytest.importorskip("genz_tokenize._native")

@@ -30,6 +30,55 @@ def sampler():
     return corpus.Sampler()
 
 
+def _run_child(cmd, name, env=None, timeout=600, cwd=None):
+    """Runs a child process of a test and KEEPS what it printed: the whole stdout / stderr go to files -- under
+    gpurun_out/children/ (that directory travels back from the GPU box), else in the system's temporary directory -- and on failure
+    the assertion message carries the HEAD and the TAIL of both streams (round 4: an abort's first lines -- "Fatal Python error",
+    the innermost frame, any HSA or glibc message -- were cut off by a tail-only message).  Python children run with the fault
+    handler on; AMD_LOG_LEVEL=1 lets the HIP runtime say which call failed.  Returns the CompletedProcess with .report set."""
+    import subprocess
+    import sys
+    import tempfile
+    env = dict(os.environ if env is None else env)
+    env.setdefault("PYTHONFAULTHANDLER", "1")
+    env.setdefault("AMD_LOG_LEVEL", "1")
+    if cmd and cmd[0] == sys.executable and "-X" not in cmd[:3]:
+        cmd = [cmd[0], "-X", "faulthandler"] + list(cmd[1:])
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    d = os.path.join(root, "gpurun_out", "children")
+    try:
+        os.makedirs(d, exist_ok=True)
+    except OSError:
+        d = tempfile.mkdtemp(prefix="gz_children_")
+    safe = "".join(ch if ch.isalnum() or ch in "-_." else "_" for ch in name)
+    po, pe = os.path.join(d, safe + ".stdout.txt"), os.path.join(d, safe + ".stderr.txt")
+    with open(po, "wb") as fo, open(pe, "wb") as fe:
+        try:
+            r = subprocess.run(cmd, env=env, cwd=cwd, stdout=fo, stderr=fe, timeout=timeout)
+            rc = r.returncode
+        except subprocess.TimeoutExpired:
+            rc = -999
+    out = open(po, "r", errors="replace").read()
+    err = open(pe, "r", errors="replace").read()
+
+    def both_ends(t, n=3000):
+        return t if len(t) <= 2 * n else t[:n] + "\n[... %d characters left out: %s ...]\n" % (len(t) - 2 * n, "see the file") + t[-n:]
+    r = subprocess.CompletedProcess(cmd, rc, out, err)
+    r.report = ("child %r: return code %s%s\n---- stdout (%s) ----\n%s\n---- stderr (%s) ----\n%s" %
+                (name, rc, " (timed out)" if rc == -999 else "", po, both_ends(out), pe, both_ends(err)))
+    return r
+
+
+def _run_selection(name, env, selection, timeout=600):
+    """A selection of this file's GPU tests once more in a child process with other switches in its environment."""
+    import sys
+    r = _run_child([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider", "-k", selection],
+                   name, env=env, timeout=timeout)
+    assert r.returncode == 0, r.report
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.report
+    return r
+
+
 def _call_matches(tok, row):
     args = list(row["args"])
     for i, isb in enumerate(row.get("bytes_args", [])):
@@ -278,32 +327,44 @@ def test_big_pipeline_on_small_inputs():
     """Small dense single-text batches run in ONE fused launch (gz_small_kernel); GZ_SMALL=0 sends them through the
     kernel pipeline instead.  The golden vectors and the small-input comparisons of this file run again that way in a
     child process, so that both forms stay pinned to the reference on the hostile small cases."""
-    import subprocess
-    import sys
     # (GZ_SCAN_MULTI=0: the block-count scans go through the chained multi-workgroup kernel whatever the size -- large
     # batches use it by default, here it also sees one-chunk and few-element inputs)
     env = dict(os.environ, GZ_SMALL="0", GZ_SCAN_MULTI="0")
-    here = os.path.abspath(__file__)
-    r = subprocess.run([sys.executable, "-m", "pytest", here, "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider", "-k",
-                        "g1_cases or g3_random or g4_loader or cfg2_10k or cfg3_20k or noisy_corpus or long_and_huge or random_tables_fuzz or extreme_batch"],
-                       env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout and "failed" not in r.stdout
+    _run_selection("big_pipeline_on_small_inputs", env,
+                   "g1_cases or g3_random or g4_loader or cfg2_10k or cfg3_20k or noisy_corpus or long_and_huge or random_tables_fuzz or extreme_batch")
+
+
+def _diag_library():
+    """build_ab/libgz_diag.so (make diag: -DGZ_DIAG), built when it is missing or older than its sources."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run(["make", "-C", os.path.join(root, "genz-tokenize_amd", "csrc"), "diag"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-3000:]
+    return os.path.join(root, "build_ab", "libgz_diag.so")
+
+
+def test_index_assertions_on_a_poisoned_workspace():
+    """The diagnostic build checks every index its kernels take out of memory against the array it goes into -- miss lists, sorted
+    miss records, word records and their token places, the wide / long word lists, first-word indices -- and a consumer that meets a
+    record no merge kernel has finished (gz_kernels.hip GZ_CHK; a failure is recorded, the access skipped, the call fails at its
+    next synchronisation).  With GZ_DIAG_POISON=1 the per-call workspace is filled with 0xFF before every call: a kernel that
+    consumes a word nobody wrote in that call then reads an impossible value EVERY time.  The selection is the one of
+    test_big_pipeline_on_small_inputs (round 4: one child of it aborted once, unexplained) plus the pair corpora: tiny batches, the
+    load-time whole-word build with its many words of 17..32 symbols, random tables, words of up to 3 000 symbols -- all through
+    the kernel pipeline, the chained scan on every size."""
+    env = dict(os.environ, GZ_LIBRARY=_diag_library(), GZ_SMALL="0", GZ_SCAN_MULTI="0", GZ_DIAG_POISON="1", GZ_BRK_SIDE="0",
+               GZ_TABLE_CACHE="off")
+    _run_selection("diag_index_assertions", env,
+                   "g1_cases or g3_random or g4_loader or cfg2_10k or cfg3_20k or noisy_corpus or noisy_pairs or long_and_huge or random_tables_fuzz or extreme_batch or not_utf8")
 
 
 def test_dense_hash_tables():
     """The long-key whole-word table (words of 17..32 bytes, linear probing) is built at 1/16 load, so its continue-probing
     branches almost never run on the default build.  GZ_TAB_SLACK=2 builds it at half load: the golden batches, the 20 k-document digests, the noisy corpora (single and
     pairs), long words and the small-kernel shapes run again that way in a child process."""
-    import subprocess
-    import sys
     env = dict(os.environ, GZ_TAB_SLACK="2")
-    here = os.path.abspath(__file__)
-    r = subprocess.run([sys.executable, "-m", "pytest", here, "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider", "-k",
-                        "g1_cases or g3_random or cfg3_20k or noisy_corpus or noisy_pairs or long_and_huge or small_kernel_shapes or random_tables_fuzz"],
-                       env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout and "failed" not in r.stdout
+    _run_selection("dense_hash_tables", env,
+                   "g1_cases or g3_random or cfg3_20k or noisy_corpus or noisy_pairs or long_and_huge or small_kernel_shapes or random_tables_fuzz")
 
 
 def test_perfect_hash_overflow_buckets_on_the_gpu():
@@ -312,15 +373,9 @@ def test_perfect_hash_overflow_buckets_on_the_gpu():
     GZ_PH_FORCE_OVERFLOW=3 makes the builder refuse every third bucket -- several thousand keys of both tables then sit in
     overflow buckets: the golden batches, the 20 k-document digests, the noisy corpora, long words and random tables run
     again that way in a child process (table cache off, so that the tables are really rebuilt)."""
-    import subprocess
-    import sys
     env = dict(os.environ, GZ_PH_FORCE_OVERFLOW="3", GZ_TABLE_CACHE="off")
-    here = os.path.abspath(__file__)
-    r = subprocess.run([sys.executable, "-m", "pytest", here, "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider", "-k",
-                        "g1_cases or g3_random or cfg3_20k or noisy_corpus or noisy_pairs or long_and_huge or random_tables_fuzz"],
-                       env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout and "failed" not in r.stdout
+    _run_selection("overflow_buckets", env,
+                   "g1_cases or g3_random or cfg3_20k or noisy_corpus or noisy_pairs or long_and_huge or random_tables_fuzz")
 
 
 @pytest.mark.parametrize("switches", [{"GZ_SIDE": "0", "GZ_BRK_SIDE": "0"}, {"GZ_ASSEMBLE": "2"}, {"GZ_ASSEMBLE": "1"},
@@ -333,15 +388,9 @@ def test_alternative_kernels_stay_exact(switches):
     sharing EVERY batch, however small and with the whole-word tables on -- by default they only do when the tables are off and
     the misses are many.  Each runs the golden batches, the 20 k-document digests, the noisy corpora, bytes that are not UTF-8
     and the long words in a child process, small batches through the pipeline."""
-    import subprocess
-    import sys
     env = dict(os.environ, GZ_SMALL="0", **switches)
-    here = os.path.abspath(__file__)
-    r = subprocess.run([sys.executable, "-m", "pytest", here, "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider", "-k",
-                        "g1_cases or g3_random_batched or cfg3_20k or noisy_corpus or long_and_huge or extreme_batch or not_utf8"],
-                       env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout and "failed" not in r.stdout
+    _run_selection("alternative_kernels_" + "_".join("%s%s" % kv for kv in sorted(switches.items())), env,
+                   "g1_cases or g3_random_batched or cfg3_20k or noisy_corpus or long_and_huge or extreme_batch or not_utf8")
 
 
 def test_far_word_records_on_small_batches():
@@ -350,15 +399,9 @@ def test_far_word_records_on_small_batches():
     below some 10 M merged words only ever produce near records: GZ_NEAR_LIMIT=300 gives the far form to every word placed
     from 300 on, so that the golden batches, the 20 k-document digests, the noisy corpora, the word-count output and the long
     words see BOTH forms side by side, in a child process with the small batches sent through the kernel pipeline."""
-    import subprocess
-    import sys
     env = dict(os.environ, GZ_NEAR_LIMIT="300", GZ_SMALL="0")
-    here = os.path.abspath(__file__)
-    r = subprocess.run([sys.executable, "-m", "pytest", here, "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider", "-k",
-                        "g1_cases or g3_random or cfg3_20k or noisy_corpus or noisy_pairs or long_and_huge or csr_host_path or large_noisy or extreme_batch"],
-                       env=env, capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert " passed" in r.stdout and "failed" not in r.stdout
+    _run_selection("far_word_records", env,
+                   "g1_cases or g3_random or cfg3_20k or noisy_corpus or noisy_pairs or long_and_huge or csr_host_path or large_noisy or extreme_batch")
 
 
 def test_small_kernel_shapes(tok, oracle_tables, sampler):
@@ -814,8 +857,8 @@ assert d3._ctx.table_cache_status() == 2 and (os.stat(os.environ["GZ_TABLE_CACHE
 print("ok build %%.3f s, cached %%.3f s" %% (ta, tb))
 """ % root
     env = dict(os.environ, GZ_TABLE_CACHE=str(tmp_path / "cache"))
-    r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=600, env=env)
-    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1].startswith("ok"), (r.stdout[-2000:], r.stderr[-3000:])
+    r = _run_child([sys.executable, "-c", child], "table_cache", env=env)
+    assert r.returncode == 0 and r.stdout.strip().splitlines()[-1].startswith("ok"), r.report
 
 
 def test_encode_batch_large_path_equals_dense_path(tok):
@@ -894,8 +937,7 @@ def test_scan_time_out_surfaces_from_every_host_path(tmp_path):
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run(["make", "-C", os.path.join(root, "genz-tokenize_amd", "csrc"), "diag"], capture_output=True, text=True, timeout=600)
-    assert r.returncode == 0, r.stderr[-2000:]
+    _diag_library()
     child = r"""
 import os, sys, ctypes as C
 import numpy as np
@@ -933,8 +975,8 @@ assert len(toks2) == n_tok and np.array_equal(toks2, toks)
 print("ok")
 """ % root
     env = dict(os.environ, GZ_LIBRARY=os.path.join(root, "build_ab", "libgz_diag.so"), GZ_SCAN_MULTI="0")
-    r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=600, env=env)
-    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-2000:], r.stderr[-2000:])
+    r = _run_child([sys.executable, "-c", child], "scan_time_out", env=env)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.report
 
 
 @pytest.mark.parametrize("world", [2, 4])
@@ -953,8 +995,8 @@ def test_bench_multirank_exchange_on_one_gpu_over_gloo(world):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", str(world), "--steps", "2", "--warmup", "1",
            "--docs", "160000", "--transport", "gloo", "--device", "0"]
-    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=420)
-    assert r.returncode == 0, r.stderr[-3000:]
+    r = _run_child(cmd, "bench_gloo_world%d" % world, env=env, timeout=420, cwd=root)
+    assert r.returncode == 0, r.report
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == world and out["config"]["shards_per_rank"] == 8 // world
@@ -978,8 +1020,8 @@ def test_bench_exchange_step_over_rccl_with_one_rank():
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1",
            "--docs", "160000", "--force-exchange", "--no-secondary"]
-    r = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=420)
-    assert r.returncode == 0, r.stderr[-3000:]
+    r = _run_child(cmd, "bench_rccl_one_rank", env=env, timeout=420, cwd=root)
+    assert r.returncode == 0, r.report
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["n_gpus"] == 1 and "RCCL gatherv" in out["config"]["sharding"]
     assert len([c for c in out["verified_items"] if c.startswith("gathered shard")]) == 8
@@ -1215,11 +1257,7 @@ def test_preprocess_fused_and_filter_by_filter_paths():
         for d, g in zip(docs, got):
             assert g == O.preprocess(d, ops), (ops, len(d.encode("utf-8")), d[-40:])
     env = dict(os.environ, GZ_PP_FUSED="0")
-    here = os.path.abspath(__file__)
-    c = subprocess.run([sys.executable, "-m", "pytest", here, "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider", "-k",
-                        "g7_preprocess or preprocess_long_documents"], env=env, capture_output=True, text=True, timeout=600)
-    assert c.returncode == 0, c.stdout[-3000:] + c.stderr[-2000:]
-    assert " passed" in c.stdout and "failed" not in c.stdout
+    _run_selection("preprocess_filter_by_filter", env, "g7_preprocess or preprocess_long_documents")
 
 
 def test_preprocess_device_size_query_and_small_capacity(tok, sampler):
@@ -1289,9 +1327,8 @@ def test_device_handoff_dlpack():
     by soname; the first one loaded serves both) -- see tests/handoff_child.py."""
     import subprocess, sys
     pytest.importorskip("torch")
-    r = subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "handoff_child.py")],
-                       capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and "HANDOFF OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    r = _run_child([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "handoff_child.py")], "handoff", timeout=300)
+    assert r.returncode == 0 and "HANDOFF OK" in r.stdout, r.report
 
 
 @pytest.mark.parametrize("seed", [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12])

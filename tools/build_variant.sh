@@ -12,7 +12,7 @@ else
   src=$tmp/genz-tokenize_amd/csrc; inc=$tmp/include
 fi
 cd $src
-id=$(cat gz_kernels.hip gz_api.cpp gz_tables.cpp gz_host_api.cpp *.h *.inc $inc/genz_tokenize.h | sha256sum | cut -c1-16)
+id=$( (cat gz_kernels.hip gz_api.cpp gz_tables.cpp gz_host_api.cpp *.h *.inc $inc/genz_tokenize.h; echo "gfx950 -O3 $*") | sha256sum | cut -c1-16)   # sources AND flags: a variant never shares cache files with another build
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-value -Wno-align-mismatch \
   -DGZ_BUILD_ID="\"$id\"" "$@" -x hip gz_kernels.hip -x hip gz_api.cpp -x hip gz_tables.cpp -x hip gz_host_api.cpp -shared -o $R/build_ab/$name.so -ldl
 echo "built build_ab/$name.so ($rev, id $id)"
