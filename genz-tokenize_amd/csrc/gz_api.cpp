@@ -98,6 +98,7 @@ struct gz_ctx {
         bool keep_words = false;
         int t_slot = 0;                // timing: the call's pair of events in the ring
         bool chained = false;          // enqueued behind a call that has not been synchronised (its scan flag is kept)
+        bool apart = false; int flip = 0;   // the row kernel on the rows stream; workspace slot of the call (option rows_apart)
         bool inputs_resident = false;  // the caller's device buffers are readable now (no copy of them is queued on the stream)
     } pend;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -118,6 +119,15 @@ struct gz_ctx {
     uint32_t lb_epoch = 0;               // call number of the chained scans (gz_scan32m_kernel)   // [slot][text]
     hipStream_t stream2 = nullptr;       // sub-batches alternate between the two streams
     hipStream_t side = nullptr;          // the wide-word kernels of a text run here, beside the merge kernel
+    // Option rows_apart: the row kernel of a dense single-text device call runs on a stream of its own; consecutive calls alternate
+    // between the two workspace slots, so the row kernel of call i (bound by its stores) runs beside the text side of call i + 1
+    // (bound by vector and LDS work) on the SAME compute units.  ev_text[slot]: the text side of the call that uses the slot is
+    // done; ev_rows[slot]: so is its row kernel (the slot's word records, token area and first-word indices may be overwritten).
+    hipStream_t rows_stream = nullptr;
+    hipEvent_t ev_text[2] = {nullptr, nullptr}, ev_rows[2] = {nullptr, nullptr};
+    bool rows_rec[2] = {false, false};
+    uint64_t apart_seq = 0;
+    bool rows_used = false;
     bool flags_lazy = false;       // the device flags of the pending chain have not been copied to h_flags yet (sync_locked does it)
     bool caller_buffers = false;   // set by the device entry points around encode_device_locked: text / offsets are the caller's
                                    // own device buffers (readable now), not staging copies queued on the stream
@@ -152,7 +162,7 @@ struct gz_ctx {
     DBuf w_stage;
     int cache_status = 0;                // of the last gz_load_tables: 0 no cache, 1 hit, 2 miss (written), 3 a file was refused (rebuilt, rewritten), 4 rebuilt but not written
     bool building_words = false;         // the whole-word table is being built: ignore diagnostics
-    bool no_words_env = false;           // GZ_WORD_TABLE=0 in the environment
+    GzOptions opt;                       // test / experiment switches (gz_debug_set): a copy of the process-wide defaults at creation
 };
 
 namespace {
@@ -229,6 +239,13 @@ int enqueue(gz_ctx* c)
     hipStream_t s = c->stream;
     const GzDeviceTables* T = (const GzDeviceTables*)c->t_struct.p;
     if (c->x_used) HIPCHK(c, hipStreamWaitEvent(s, c->ev_x, 0));    // output buffers may still be read by an exchange step
+    if (c->rows_used) {
+        // row kernels of earlier calls may still run on the rows stream: a call of the same kind waits for the one that used ITS
+        // workspace slot (two calls back); any other call waits for all of them
+        if (p.apart) { if (c->rows_rec[p.flip]) HIPCHK(c, hipStreamWaitEvent(s, c->ev_rows[p.flip], 0)); }
+        else for (int i = 0; i < 2; ++i) if (c->rows_rec[i]) HIPCHK(c, hipStreamWaitEvent(s, c->ev_rows[i], 0));
+    }
+    if (p.apart && c->x_used) HIPCHK(c, hipStreamWaitEvent(c->rows_stream, c->ev_x, 0));
     const bool no_flags = p.small && !p.ragged;                 // (a dense one-launch call raises no flag)
     // [0] scan time-out, [1] capacity error, [3] a word needs the wide / long kernels.  Calls chained without a host
     // synchronisation keep [0]: it is only cleared when a chain starts, so a time-out in ANY call of the chain is still
@@ -257,13 +274,19 @@ int enqueue(gz_ctx* c)
     for (size_t k = 0; k < p.subs.size(); ++k) {
         hipStream_t sk = (k & 1) ? c->stream2 : s;
         const GzAsmArgs& S = p.subs[k];
+        const int e = (int)((k + (size_t)p.flip) & 1);           // the workspace slot, and its events
         for (int tx = 0; tx < S.n_texts; ++tx)
-            gz_launch_pipeline_text(T, c->dev, S.X[tx], S.n_docs, p.use_words, (int32_t*)c->w_flags.p + 3, sk, c->side, c->ev_sf0[k & 1][tx], c->ev_sf[k & 1][tx], c->ev_sj[k & 1][tx],
-                                    p.inputs_resident ? c->ev_sb[k & 1][tx] : nullptr);
-        gz_launch_assemble(T, S, sk);
+            gz_launch_pipeline_text(c->opt, T, c->dev, S.X[tx], S.n_docs, p.use_words, (int32_t*)c->w_flags.p + 3, sk, c->side, c->ev_sf0[e][tx], c->ev_sf[e][tx], c->ev_sj[e][tx],
+                                    p.inputs_resident ? c->ev_sb[e][tx] : nullptr);
+        if (p.apart) {
+            HIPCHK(c, hipEventRecord(c->ev_text[p.flip], s)); HIPCHK(c, hipStreamWaitEvent(c->rows_stream, c->ev_text[p.flip], 0));
+            gz_launch_assemble(c->opt, T, S, c->rows_stream);
+            HIPCHK(c, hipEventRecord(c->ev_rows[p.flip], c->rows_stream));
+            c->rows_rec[p.flip] = true; c->rows_used = true;
+        } else gz_launch_assemble(c->opt, T, S, sk);
     }
     if (two) { HIPCHK(c, hipEventRecord(c->ev_join, c->stream2)); HIPCHK(c, hipStreamWaitEvent(s, c->ev_join, 0)); }
-    if (p.timing) { p.t_slot = (int)(c->ring_n % gz_ctx::RING); HIPCHK(c, hipEventRecord(c->ring[p.t_slot][1], s)); c->ring_n++; }
+    if (p.timing) { p.t_slot = (int)(c->ring_n % gz_ctx::RING); HIPCHK(c, hipEventRecord(c->ring[p.t_slot][1], p.apart ? c->rows_stream : s)); c->ring_n++; }
     if (p.ragged) {
         gz_launch_rowscan(p.F, (int64_t*)c->w_rowlen.p, s);
         gz_launch_finalize(c->dev, p.F, s);
@@ -274,7 +297,7 @@ int enqueue(gz_ctx* c)
     if (lazy_flags) c->flags_lazy = true;
     else if (!no_flags) { HIPCHK(c, hipMemcpyAsync(c->h_flags, c->w_flags.p, 8, hipMemcpyDeviceToHost, s)); c->flags_lazy = false; }
     else if (!p.chained) c->h_flags[0] = c->h_flags[1] = 0;
-    HIPCHK(c, hipEventRecord(c->ev_tok[c->enc_seq & 3], s));
+    HIPCHK(c, hipEventRecord(c->ev_tok[c->enc_seq & 3], p.apart ? c->rows_stream : s));
     c->enc_seq++;
     HIPCHK(c, hipGetLastError());
     return GZ_OK;
@@ -306,6 +329,7 @@ int sync_locked(gz_ctx* c)
         HIPCHK(c, hipMemcpyAsync(c->h_flags, c->w_flags.p, 8, hipMemcpyDeviceToHost, c->stream));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    if (c->rows_used) { HIPCHK(c, hipStreamSynchronize(c->rows_stream)); c->rows_used = false; c->rows_rec[0] = c->rows_rec[1] = false; }
     if (c->x_used) HIPCHK(c, hipStreamSynchronize(c->xstream));
 #ifdef GZ_DIAG
     {
@@ -358,10 +382,8 @@ int setup_text(gz_ctx* c, gz_ctx::TextWs& W, DBuf& tiny, const uint8_t* tb, cons
     X.off = off;
     X.B = Bt;
     {
-        // near records (gz_pipeline.inc, W_NEAR): GZ_NEAR_LIMIT shrinks the range so that small test batches reach the far form
-        uint32_t lim = 1u << 25;
-        if (const char* e = getenv("GZ_NEAR_LIMIT")) { const long v = atol(e); if (v >= 0 && v < (long)lim) lim = (uint32_t)v; }
-        X.near_lim = lim;
+        // near records (gz_pipeline.inc, W_NEAR): the option near_limit shrinks the range so that small test batches reach the far form
+        X.near_lim = (uint32_t)c->opt.near_limit;
     }
     X.nblk = Bt / 4096 + 1;
     const size_t bm = (size_t)((Bt + 1024) / 1024) * 128 + 64 + 4096;
@@ -381,12 +403,11 @@ int setup_text(gz_ctx* c, gz_ctx::TextWs& W, DBuf& tiny, const uint8_t* tb, cons
         return rc2;
 #ifdef GZ_DIAG
     {
-        // GZ_DIAG_POISON=1 (diagnostic build): the whole per-call workspace is filled with 0xFF before every call, so that a kernel
+        // option diag_poison (diagnostic build): the whole per-call workspace is filled with 0xFF before every call, so that a kernel
         // that consumes a word nobody wrote in THIS call reads an impossible index or a pending record every time, not just when the
-        // allocation happens to hold one (run with GZ_BRK_SIDE=0: the start bits are then cleared on this stream, behind the fill).
+        // allocation happens to hold one (run with brk_side = 0: the start bits are then cleared on this stream, behind the fill).
         // The chained scans' words are left alone: they are validated by their call number.
-        static const bool poison = getenv("GZ_DIAG_POISON") && atoi(getenv("GZ_DIAG_POISON")) != 0;
-        if (poison)
+        if (c->opt.diag_poison)
             for (DBuf* b : {&W.brk, &W.st, &W.en, &W.blkcnt, &W.docw0, &W.wtok, &W.waux, &W.mtok, &W.mlist, &W.grpblk, &W.blkmiss, &W.tilecnt, &W.wlist, &W.mq})
                 HIPCHK(c, hipMemsetAsync(b->p, 0xFF, b->cap, s));
     }
@@ -420,12 +441,11 @@ bool ids_fit_16(gz_ctx* c)
 int use_words_flags(gz_ctx* c, uint32_t flags)
 {
 #ifdef GZ_DIAG
-    const char* ab = getenv("GZ_ABLATE");       // timing diagnostics only (diagnostic builds): results are wrong when set
-    const int ablate = (ab && !c->building_words) ? atoi(ab) : 0;
+    const int ablate = c->building_words ? 0 : c->opt.ablate;       // timing diagnostics only (diagnostic builds): results are wrong when set
 #else
     const int ablate = 0;
 #endif
-    const int use_words = (c->dev.words0p != nullptr && !(flags & GZ_NO_WORD_TABLE) && !c->no_words_env) ? 1 : 0;
+    const int use_words = (c->dev.words0p != nullptr && !(flags & GZ_NO_WORD_TABLE) && c->opt.word_table) ? 1 : 0;
     return use_words | (ablate << 8);
 }
 
@@ -464,9 +484,8 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
     // Sub-batches: contiguous document ranges (dense layouts of large batches only).  Their byte positions are the
     // only thing the host needs to know about the offsets: one tiny kernel + one 8*(2*nsub+2)-byte copy.
     // (measured on cfg 3: 2 sub-batches on two streams gain 1.5 %, 4 gain nothing, 8 lose 10 % -- the kernels of one
-    // sub-batch already fill the chip -- so the default is one batch; GZ_SUB_BATCHES=k is kept for experiments)
-    int nsub = 1;
-    if (const char* e = getenv("GZ_SUB_BATCHES")) { int v = atoi(e); if (v >= 1 && v <= 8) nsub = (dense && n_docs >= 8 * v) ? v : 1; }
+    // sub-batch already fill the chip -- so the default is one batch; the option sub_batches is kept for experiments)
+    int nsub = (dense && n_docs >= 8 * (int64_t)c->opt.sub_batches) ? c->opt.sub_batches : 1;
     int64_t cutA[9], cutB[9];
     if (h_text_off) {
         for (int k = 0; k <= nsub; ++k) {
@@ -493,7 +512,7 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
         if (dpw > by_waves) dpw = by_waves;
         if (dpw < 1) dpw = 1;
         if (dpw > GZ_MAX_DOCS_PER_WAVE) dpw = GZ_MAX_DOCS_PER_WAVE;
-        if (const char* e = getenv("GZ_DOCS_PER_WAVE")) { int v = atoi(e); if (v >= 1 && v <= GZ_MAX_DOCS_PER_WAVE) dpw = v; }
+        if (c->opt.docs_per_wave >= 1 && c->opt.docs_per_wave <= GZ_MAX_DOCS_PER_WAVE) dpw = c->opt.docs_per_wave;
         docs_per_wave = (int)dpw;
         p.use_words = use_words_flags(c, flags);
     }
@@ -512,9 +531,8 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
     {
         // Small batches run in ONE launch that cuts the work by documents (gz_small.inc): single texts or pairs whose
         // longest document fits a workgroup's LDS (ragged layouts: the unpadded rows go to the raw area, finalize follows as in
-        // the big path).  The host needs the document sizes for that, so only calls that bring host offsets qualify.  GZ_SMALL=0 switches the path off (tests run the golden batches both ways).
-        static const int small_on = getenv("GZ_SMALL") ? atoi(getenv("GZ_SMALL")) : 1;
-        if (small_on && h_text_off && !p.keep_words && n_docs > 0 && n_docs <= (1 << 20) && text_bytes + pair_bytes <= (2ll << 20)) {
+        // the big path).  The host needs the document sizes for that, so only calls that bring host offsets qualify.  The option small = 0 switches the path off (tests run the golden batches both ways).
+        if (c->opt.small && h_text_off && !p.keep_words && n_docs > 0 && n_docs <= (1 << 20) && text_bytes + pair_bytes <= (2ll << 20)) {
             int64_t maxdoc = 0, maxpair = 0;
             for (int64_t d = 0; d < n_docs; ++d) {
                 const int64_t b = h_text_off[d + 1] - h_text_off[d]; if (b > maxdoc) maxdoc = b;
@@ -526,7 +544,7 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
                 if (G > GZ_SMALL_DOCS_PER_WG) G = GZ_SMALL_DOCS_PER_WG;
                 // a batch this small cannot fill the chip with full groups: more, smaller workgroups (each phase of a workgroup
                 // is a dependent chain, so the call's time is the time of ONE workgroup)
-                static const int64_t wg_target = getenv("GZ_SMALL_WGS") ? atoi(getenv("GZ_SMALL_WGS")) : 768;
+                const int64_t wg_target = c->opt.small_wgs;
                 const int64_t by_chip = (n_docs + wg_target - 1) / wg_target;
                 if (G > by_chip) G = by_chip;
                 gz_ctx::TextWs& W = c->tw[0][0];
@@ -540,6 +558,14 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
             }
         }
     }
+    // (rows_apart: dense single texts from the caller's own device buffers, with host offsets -- the calls that can be chained)
+    p.apart = c->opt.rows_apart && nsub == 1 && dense && !is_pair && !p.keep_words && c->caller_buffers && h_text_off && c->opt.assemble >= 3 &&
+              max_len >= 4 && (max_len & 3) == 0 && max_len <= 1024;
+    if (p.apart && !c->rows_stream) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->rows_stream, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) { HIPCHK(c, hipEventCreateWithFlags(&c->ev_text[i], hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_rows[i], hipEventDisableTiming)); }
+    }
+    p.flip = p.apart ? (int)(c->apart_seq++ & 1) : 0;
     p.subs.resize((size_t)nsub);
     for (int k = 0; k < nsub; ++k) {
         const int64_t lo = (int64_t)k * n_docs / nsub, hi = (int64_t)(k + 1) * n_docs / nsub;
@@ -552,7 +578,7 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
         S2.docs_per_wave = docs_per_wave;
         for (int tx = 0; tx < S2.n_texts; ++tx) {
             const int64_t* cut = tx ? cutB : cutA;
-            int rc2 = setup_text(c, c->tw[k & 1][tx], c->w_tiny[k & 7][tx], (tx ? pair : text) + cut[k], (tx ? pair_off : text_off) + lo,
+            int rc2 = setup_text(c, c->tw[(k + p.flip) & 1][tx], c->w_tiny[(k + p.flip) & 7][tx], (tx ? pair : text) + cut[k], (tx ? pair_off : text_off) + lo,
                                  cut[k + 1] - cut[k], S2.n_docs, c->stream, S2.X[tx]);
             if (rc2) return rc2;
         }
@@ -672,7 +698,7 @@ static int build_word_table(gz_ctx* c, WordImages& W)
             size_t rising = 0;
             for (size_t i = 0; i < H.enc_count.size(); ++i) { any |= H.enc_count[i] != 0; rising += i > 5 && H.enc_count[i] > H.enc_count[i - 1]; }
             bool by_count = any && rising * 100 <= H.enc_count.size();
-            if (const char* e = getenv("GZ_WORD_WEIGHTS")) by_count = any && e[0] == 'c';       // (A/B: "counts" / "merges")
+            if (gz_default_options().word_weights) by_count = any && gz_default_options().word_weights == 1;       // (A/B: 1 counts, 2 merge ranks)
             std::vector<uint64_t> weight_of_id(H.enc_words.size(), 0);          // (ids are sizes of the dict at insertion: < its size)
             if (by_count)
                 for (size_t i = 0; i < H.enc_words.size(); ++i) {
@@ -785,7 +811,7 @@ int gz_create(int device_id, gz_ctx** out)
     }
     std::memset(c->h_flags, 0, 64);
     phase("device, first stream, pinned flags");
-    if (const char* e = getenv("GZ_WORD_TABLE")) c->no_words_env = (e[0] == '0');
+    c->opt = gz_default_options();
     for (auto& ev : c->ev) hipEventCreate(&ev);
     hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
     hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
@@ -816,6 +842,8 @@ void gz_destroy(gz_ctx* c)
     if (c->ev_x) hipEventDestroy(c->ev_x);
     if (c->xstream) hipStreamDestroy(c->xstream);
     if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
+    if (c->rows_stream) { hipStreamSynchronize(c->rows_stream); hipStreamDestroy(c->rows_stream); }
+    for (int i = 0; i < 2; ++i) { if (c->ev_text[i]) hipEventDestroy(c->ev_text[i]); if (c->ev_rows[i]) hipEventDestroy(c->ev_rows[i]); }
     for (auto& a : c->ev_sf0) for (auto& e : a) if (e) hipEventDestroy(e);
     for (auto& a : c->ev_sb) for (auto& e : a) if (e) hipEventDestroy(e);
     for (auto& a : c->ev_sf) for (auto& e : a) if (e) hipEventDestroy(e);
@@ -934,6 +962,16 @@ int gz_load_tables(gz_ctx* c, const uint8_t* vocab, size_t vocab_len, const uint
         if (!written) c->cache_status = 4;                       // 4: rebuilt, and the file could NOT be written (directory missing / shared / full)
         phase("cache write");
     }
+    return GZ_OK;
+}
+
+int gz_debug_set(gz_ctx* c, const char* key, int64_t value)
+{
+    // c == NULL: the process-wide defaults (contexts created from now on, and the table builder); else this context
+    int rc;
+    if (c) { std::lock_guard<std::mutex> lk(c->mu); rc = gz_option_set(c->opt, key, value); }
+    else rc = gz_option_set(gz_default_options(), key, value);
+    if (rc) return fail(c, GZ_E_INVALID, "gz_debug_set: unknown key or value out of range: %s = %lld", key ? key : "(null)", (long long)value);
     return GZ_OK;
 }
 
@@ -1348,8 +1386,8 @@ int gz_encode_batch_csr(gz_ctx* c, const uint8_t* text, const int64_t* text_off,
             hipStreamSynchronize(c->s_in); hipStreamSynchronize(s); hipStreamSynchronize(c->s_out);
             return rc;
         }
-        gz_launch_pipeline_text(T, c->dev, A.X[0], A.n_docs, use_words, (int32_t*)c->w_flags.p + 3, s, c->side, c->ev_sf0[k & 1][0], c->ev_sf[k & 1][0], c->ev_sj[k & 1][0]);
-        gz_launch_assemble(T, A, s);
+        gz_launch_pipeline_text(c->opt, T, c->dev, A.X[0], A.n_docs, use_words, (int32_t*)c->w_flags.p + 3, s, c->side, c->ev_sf0[k & 1][0], c->ev_sf[k & 1][0], c->ev_sj[k & 1][0]);
+        gz_launch_assemble(c->opt, T, A, s);
         uint32_t* off32 = (uint32_t*)c->w_csr_off32.p;
         gz_launch_row_offsets(A.n_real, A.n_docs, off32, s);
         gz_launch_compact(A.ids, off32, A.n_docs, max_len, (uint8_t*)c->w_csr_comp.p + (size_t)bound[(size_t)k] * esz, bits, s);
@@ -1490,6 +1528,13 @@ int gz_timing_history(gz_ctx* c, double* out_ms, int32_t max, int32_t* n_out)
         const uint64_t k = c->ring_n - (uint64_t)n + (uint64_t)i;
         float ms = 0;
         HIPCHK(c, hipEventElapsedTime(&ms, c->ring[k % gz_ctx::RING][0], c->ring[k % gz_ctx::RING][1]));
+        // a call whose kernels began before the call before it had ended (rows_apart: its text side runs beside that call's row
+        // kernel) is charged from that call's END: the durations of a chain then add up to the chain's span, never to more
+        if (i > 0) {
+            float since_prev = 0;
+            HIPCHK(c, hipEventElapsedTime(&since_prev, c->ring[(k - 1) % gz_ctx::RING][1], c->ring[k % gz_ctx::RING][1]));
+            if (since_prev > 0 && since_prev < ms) ms = since_prev;
+        }
         out_ms[i] = ms;
     }
     *n_out = n;
@@ -1647,12 +1692,11 @@ int preprocess_device_locked(gz_ctx* c, const int32_t* ops, int32_t n_ops, const
     }
     const uint8_t* in = text_dev;
     const int64_t* in_len = nullptr;
-    // documents of at most 4 KiB: the whole chain in one kernel, on chip (GZ_PP_FUSED=0: filter by filter like the long ones)
+    // documents of at most 4 KiB: the whole chain in one kernel, on chip (option pp_fused = 0: filter by filter like the long ones)
     // (the fused kernel's tail -- lengths, their scan, the pack kernel's offsets, the total -- is 32-bit: filters never grow a
     // document, so it is exact while the INPUT stays under 4 GiB; a larger input takes the filter-by-filter chain with its 64-bit
     // scan and pack kernels)
-    static const int fused_env = getenv("GZ_PP_FUSED") ? atoi(getenv("GZ_PP_FUSED")) : 1;
-    const bool fused = fused_env != 0 && gz_pp_tail_is_32bit(in_bytes);
+    const bool fused = c->opt.pp_fused != 0 && gz_pp_tail_is_32bit(in_bytes);
     if (fused && n_docs > 0) {
         GzPpFusedArgs F{};
         F.in = text_dev; F.in_off = off_dev; F.n_docs = n_docs;

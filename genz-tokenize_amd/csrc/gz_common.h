@@ -41,22 +41,49 @@ GZ_HD uint32_t gz_cp_hash(uint32_t cp)
     return h ^ (h >> 16);
 }
 
-// The long-key whole-word table (words of 17..32 bytes, probed once per MISS) is a plain open-addressing table: slots >=
-// GZ_TAB_SLACK x entries, rounded up to a power of two.  (The environment variable GZ_TAB_SLACK = 2 .. 64 overrides it when
-// the tables are built: the parity suite runs its golden batches once more at half load, where probe chains are long, so
-// that the continue-probing paths stay exercised.)
+// ---------------------------------------------------------------------------------------------------------
+// The library's switches for tests and experiments (gz_debug_set, include/genz_tokenize.h).  Typed, named, with the product's
+// behaviour as the default; NOTHING here is read from the environment.  A context copies the process-wide defaults when it is
+// created (gz_debug_set(NULL, ...) changes those; gz_debug_set(ctx, ...) one context).  The keys marked "builder" act where the
+// tables are built, which has no context: they are read from the process-wide defaults at that moment.
+// ---------------------------------------------------------------------------------------------------------
 #ifndef GZ_TAB_SLACK
 #define GZ_TAB_SLACK 16
 #endif
-inline size_t gz_tab_slack()
-{
-    static const size_t v = [] {
-        const char* e = getenv("GZ_TAB_SLACK");
-        const long k = e ? atol(e) : 0;
-        return (size_t)(k >= 2 && k <= 64 ? k : GZ_TAB_SLACK);
-    }();
-    return v;
-}
+struct GzOptions {
+    // ---- which kernels a call takes
+    int32_t small = 1;                // 1: small dense / ragged batches in ONE launch (gz_small_kernel); 0: everything through the kernel pipeline
+    int32_t small_wgs = 768;          // workgroups the one-launch kernel aims for
+    int32_t assemble = 3;             // row writer of dense single texts: 3 gz_rows1_kernel, 2 the pair-mode kernel (rows through LDS), 1 the ragged layouts' scatter kernel
+    int32_t word_table = 1;           // 0: every word through the merge loop (as GZ_NO_WORD_TABLE on every call)
+    int32_t pp_fused = 1;             // 0: the text pre-pass filter by filter for every document
+    int32_t sub_batches = 1;          // dense batches cut into this many document ranges on two streams (1 .. 8)
+    int32_t docs_per_wave = 0;        // documents per wave of gz_assemble_kernel (0: by the batch's shape)
+    // ---- how the pipeline of one text is scheduled
+    int32_t side = 1;                 // 0: no side stream (docw0, wide / long words on the main stream)
+    int32_t brk_side = 1;             // 0: document-start bits and control words prepared on the main stream
+    int64_t scan_multi = 8192;        // block counts from which the chained multi-workgroup scan is used (0: always)
+    int64_t near_limit = 1 << 25;     // token places below this get near records (smaller: the far form on small batches)
+    int32_t hot_wgs = 0;              // grid of gz_words2_kernel (0: as many workgroups as the chip holds)
+    int32_t hot_miss_wgs = 0;         // grid of gz_miss2_kernel (0: as above)
+    int64_t m2_split_min = 65536;     // chunks of misses from which the merge kernel's two instances share a launch (0: never)
+    int32_t m2_split_always = 0;      // 1: ... also with the whole-word tables on
+    int32_t rows_apart = 0;           // 1: the row kernel of a dense device call on a stream of its own, beside the NEXT call's text side (two workspace slots)
+    // ---- builder (process-wide: read when tables are built)
+    int32_t tab_slack = GZ_TAB_SLACK; // long-key whole-word table: slots >= this x entries (2 .. 64)
+    int32_t ph_force_overflow = 0;    // k > 0: the perfect-hash builder refuses every k-th bucket (overflow paths of the kernels)
+    int32_t ph_hot_slots = 1024;      // slots at the head of the whole-word table reserved for the most frequent words (0 .. 8192)
+    int32_t word_weights = 0;         // frequency estimate of whole words: 0 auto, 1 the vocab file's counts, 2 merge ranks
+    // ---- diagnostic build only (results are WRONG with ablate / rows_dbg)
+    int32_t diag_poison = 0, rows_dpw = 0, rows_dbg = 0, ablate = 0;
+};
+GzOptions& gz_default_options();                                          // gz_host_api.cpp
+int gz_option_set(GzOptions& o, const char* key, int64_t value);           // GZ_OK, or GZ_E_INVALID for an unknown key / a value out of range
+
+// The long-key whole-word table (words of 17..32 bytes, probed once per MISS) is a plain open-addressing table: slots >=
+// tab_slack x entries, rounded up to a power of two.  (The parity suite runs its golden batches once more at half load, where probe
+// chains are long, so that the continue-probing paths stay exercised.)
+inline size_t gz_tab_slack() { return (size_t)gz_default_options().tab_slack; }
 
 // ---------------------------------------------------------------------------------------------------------
 // Static perfect hashing (hash and displace) for the tables the two hot kernels probe once per word / once per
@@ -140,17 +167,8 @@ GZ_HD uint32_t gz_word1_ha(uint64_t lo, uint64_t hi, uint32_t len, uint32_t k1, 
     return gz_word1_ha_of(gz_word1_hb(lo, hi, len, k1, k2));
 }
 
-// slots at the head of the whole-word table that the builder reserves for the most frequent words (GZ_PH_HOT_SLOTS = 0 .. 8192
-// overrides it when the tables are built; 0: no steering)
-inline uint32_t gz_word_hot_slots()
-{
-    static const uint32_t v = [] {
-        const char* e = getenv("GZ_PH_HOT_SLOTS");
-        const long k = e ? atol(e) : -1;
-        return (uint32_t)(k >= 0 && k <= 8192 ? k : 1024);
-    }();
-    return v;
-}
+// slots at the head of the whole-word table that the builder reserves for the most frequent words (0: no steering)
+inline uint32_t gz_word_hot_slots() { return (uint32_t)gz_default_options().ph_hot_slots; }
 
 // Device-resident tables, passed to kernels by value.
 struct GzDeviceTables {

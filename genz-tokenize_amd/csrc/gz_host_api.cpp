@@ -5,6 +5,7 @@
 #include "../../include/genz_tokenize.h"
 #include "gz_common.h"
 
+#include <cstring>
 #include <new>
 #include <string>
 
@@ -14,9 +15,50 @@ std::string& gz_create_err()
     return err;
 }
 
+GzOptions& gz_default_options()
+{
+    static GzOptions o;
+    return o;
+}
+
+int gz_option_set(GzOptions& o, const char* key, int64_t v)
+{
+    if (!key) return GZ_E_INVALID;
+    struct Key { const char* name; int32_t GzOptions::*p32; int64_t GzOptions::*p64; int64_t lo, hi; };
+    static const Key keys[] = {
+        {"small", &GzOptions::small, nullptr, 0, 1}, {"small_wgs", &GzOptions::small_wgs, nullptr, 1, 1 << 20},
+        {"assemble", &GzOptions::assemble, nullptr, 1, 3}, {"word_table", &GzOptions::word_table, nullptr, 0, 1},
+        {"pp_fused", &GzOptions::pp_fused, nullptr, 0, 1}, {"sub_batches", &GzOptions::sub_batches, nullptr, 1, 8},
+        {"docs_per_wave", &GzOptions::docs_per_wave, nullptr, 0, 16}, {"side", &GzOptions::side, nullptr, 0, 1},
+        {"brk_side", &GzOptions::brk_side, nullptr, 0, 1}, {"scan_multi", nullptr, &GzOptions::scan_multi, 0, (int64_t)1 << 40},
+        {"near_limit", nullptr, &GzOptions::near_limit, 0, 1 << 25}, {"hot_wgs", &GzOptions::hot_wgs, nullptr, 0, 1 << 16},
+        {"hot_miss_wgs", &GzOptions::hot_miss_wgs, nullptr, 0, 1 << 16}, {"m2_split_min", nullptr, &GzOptions::m2_split_min, 0, (int64_t)1 << 32},
+        {"m2_split_always", &GzOptions::m2_split_always, nullptr, 0, 1}, {"rows_apart", &GzOptions::rows_apart, nullptr, 0, 1},
+        {"tab_slack", &GzOptions::tab_slack, nullptr, 2, 64}, {"ph_force_overflow", &GzOptions::ph_force_overflow, nullptr, 0, 1 << 20},
+        {"ph_hot_slots", &GzOptions::ph_hot_slots, nullptr, 0, 8192}, {"word_weights", &GzOptions::word_weights, nullptr, 0, 2},
+        {"diag_poison", &GzOptions::diag_poison, nullptr, 0, 1}, {"rows_dpw", &GzOptions::rows_dpw, nullptr, 0, 64},
+        {"rows_dbg", &GzOptions::rows_dbg, nullptr, 0, 255}, {"ablate", &GzOptions::ablate, nullptr, 0, 1 << 20},
+    };
+    for (const Key& k : keys)
+        if (std::strcmp(k.name, key) == 0) {
+            if (v < k.lo || v > k.hi) return GZ_E_INVALID;
+            if (k.p32) o.*(k.p32) = (int32_t)v; else o.*(k.p64) = v;
+            return GZ_OK;
+        }
+    return GZ_E_INVALID;
+}
+
 extern "C" {
 
 #ifdef GZ_HOST_ONLY
+// (no contexts in the sanitizer build: every key goes to the process-wide defaults, which the table builder reads)
+int gz_debug_set(gz_ctx*, const char* key, int64_t value)
+{
+    const int rc = gz_option_set(gz_default_options(), key, value);
+    if (rc) gz_create_err() = std::string("gz_debug_set: unknown key or value out of range: ") + (key ? key : "(null)");
+    return rc;
+}
+
 // the sanitizer build has no contexts: only the two context-free entry points of the main library
 int gz_version(void) { return GZ_VERSION; }
 const char* gz_last_error(gz_ctx*) { return gz_create_err().c_str(); }

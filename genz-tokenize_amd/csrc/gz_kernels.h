@@ -77,7 +77,7 @@ struct GzAsmArgs {
 // T_host: the host copy of the table descriptor (table sizes decide launch shapes)
 // side / ev_fork0 / ev_fork / ev_join (may be null): a second stream on which gz_docw0_kernel runs beside the word kernel and
 // the rare wide-word kernels beside the merge kernel
-void gz_launch_pipeline_text(const GzDeviceTables* T_dev, const GzDeviceTables& T_host, const GzTextBufs& X, int64_t n_docs, int use_words,
+void gz_launch_pipeline_text(const GzOptions& O, const GzDeviceTables* T_dev, const GzDeviceTables& T_host, const GzTextBufs& X, int64_t n_docs, int use_words,
                              int32_t* long_flag /* device int, zeroed by the caller */, hipStream_t s,
                              hipStream_t side = nullptr, hipEvent_t ev_fork0 = nullptr, hipEvent_t ev_fork = nullptr, hipEvent_t ev_join = nullptr,
                              hipEvent_t ev_brk = nullptr /* non-null: X.off is readable NOW (no copy of it is queued on s): the document-start
@@ -87,7 +87,7 @@ void gz_launch_row_offsets(const int32_t* n_real, int64_t n_rows, uint32_t* off,
 void gz_launch_compact(const int32_t* rows, const uint32_t* off, int64_t n_rows, int32_t row_len, void* out, int bits /* 32 | 16 */, hipStream_t s);
 void gz_launch_expand(const void* compact, int bits, const uint32_t* off, int64_t n_rows, int32_t row_len, int32_t pad_id, int32_t* ids,
                       int32_t* mask, hipStream_t s);
-void gz_launch_assemble(const GzDeviceTables* T_dev, const GzAsmArgs& A, hipStream_t s);
+void gz_launch_assemble(const GzOptions& O, const GzDeviceTables* T_dev, const GzAsmArgs& A, hipStream_t s);
 // small batches, one launch (gz_small.inc): G documents per workgroup, G <= GZ_SMALL_DOCS_PER_WG and every group of G
 // documents (A and B texts together) <= GZ_SMALL_DOC_BYTES.  poff == nullptr: single texts.  dense: rows of max_len into
 // ids / mask; else: unpadded rows into the raw area `ids` (document d at (bytes before d) + 2 d per text) and their

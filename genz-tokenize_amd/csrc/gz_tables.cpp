@@ -474,7 +474,7 @@ void gz_ph_build(size_t n, void (*hashes)(const void* ctx, size_t i, uint32_t k1
     while ((size_t(1) << (32 - sshift)) < slots) --sshift;
     size_t nb0 = 16;
     while (nb0 * 8 < n) nb0 <<= 1;
-    static const int force = [] { const char* e = getenv("GZ_PH_FORCE_OVERFLOW"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 0; }();
+    const int force = gz_default_options().ph_force_overflow;      // (tests: every force-th bucket is refused)
     const uint32_t hzone = (hot && hot_slots < slots / 4) ? hot_slots : 0u;        // (a region that is a large part of the table steers nothing)
     GzPhHost best;
     std::vector<uint32_t> best_slots;

@@ -29,7 +29,7 @@ SYMBOLS = [
     "gz_timing", "gz_timing_history", "gz_decoder_snapshot", "gz_decode_batch", "gz_decode_batch_device", "gz_preprocess_batch",
     "gz_preprocess_batch_device", "gz_block_create", "gz_block_release", "gz_block_dlpack", "gz_dlpack_capsule_destructor", "gz_exchange_select", "gz_comm_unique_id", "gz_comm_init", "gz_gather_rows", "gz_compact_rows", "gz_expand_rows", "gz_compact_rows16", "gz_expand_rows16", "gz_compact_block", "gz_expand_block",
     "gz_host_tables_create", "gz_host_tables_destroy", "gz_host_tables_array", "gz_host_tables_vocab_entry",
-    "gz_host_tables_merge_entry", "gz_host_tables_symbol", "gz_limit",
+    "gz_host_tables_merge_entry", "gz_host_tables_symbol", "gz_limit", "gz_debug_set",
 ]
 
 _lib = None
@@ -113,8 +113,19 @@ def load_library():
     if hasattr(L, "gz_limit"):
         L.gz_limit.argtypes = [C.c_int]
         L.gz_limit.restype = i64
+    if hasattr(L, "gz_debug_set"):
+        L.gz_debug_set.argtypes = [vp, C.c_char_p, i64]
     _lib = L
     return L
+
+
+def debug_set(key: str, value: int, ctx: "Context | None" = None):
+    """gz_debug_set: a test / experiment switch of the library -- of one context, or (ctx None) the process-wide defaults that
+    contexts created afterwards copy and the table builder reads.  Raises ValueError for an unknown key or a bad value."""
+    lib = load_library()
+    rc = lib.gz_debug_set(ctx.handle if ctx is not None else None, key.encode("ascii"), int(value))
+    if rc != GZ_OK:
+        raise ValueError("gz_debug_set(%r, %r): unknown key or value out of range" % (key, value))
 
 
 def _ptr(a):

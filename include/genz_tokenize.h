@@ -214,6 +214,29 @@ int  gz_host_tables_symbol(gz_host_tables *t, int32_t symbol, const uint8_t **ut
  * below 2^32.  Unknown `which`: -1. */
 int64_t gz_limit(int which);
 
+/* Switches for tests and experiments: typed, named, range-checked -- the library reads NONE of them from the environment (its
+ * documented environment is GZ_TABLE_CACHE, GZ_LOAD_TIMING, and for the Python package GZ_LIBRARY and GZ_PACK_THREADS).
+ * ctx == NULL sets the process-wide defaults, which every context created afterwards copies and which the table builder reads
+ * (the "builder" keys act only there); ctx != NULL sets one context.  The defaults are the product's behaviour.  Keys
+ * (value range; default):
+ *   small (0..1; 1)            small batches in one launch; 0: everything through the kernel pipeline
+ *   small_wgs (1..2^20; 768)   workgroups the one-launch kernel aims for
+ *   assemble (1..3; 3)         row writer of dense single texts: 3 rows1, 2 the pair-mode kernel, 1 the ragged layouts' scatter kernel
+ *   word_table (0..1; 1)       0: every word through the merge loop (as GZ_NO_WORD_TABLE on every call)
+ *   pp_fused (0..1; 1)         0: the text pre-pass filter by filter for every document
+ *   sub_batches (1..8; 1)      dense batches cut into document ranges on two streams
+ *   docs_per_wave (0..16; 0)   documents per wave of the ragged row writer (0: by the batch's shape)
+ *   side, brk_side (0..1; 1)   0: no side stream / control words prepared on the main stream
+ *   scan_multi (>= 0; 8192)    block counts from which the chained multi-workgroup scan runs (0: always)
+ *   near_limit (0..2^25; 2^25) token places below this get near records
+ *   hot_wgs, hot_miss_wgs (0..65536; 0)   grids of the word / merge kernels (0: as many workgroups as the chip holds)
+ *   m2_split_min (>= 0; 65536), m2_split_always (0..1; 0)   when the merge kernel's two instances share a launch
+ *   rows_apart (0..1; 0)       the row kernel of a dense device call on its own stream beside the next call's text side
+ *   builder: tab_slack (2..64; 16), ph_force_overflow (>= 0; 0), ph_hot_slots (0..8192; 1024), word_weights (0..2; 0)
+ *   diagnostic build only: diag_poison (0..1), rows_dpw, rows_dbg, ablate
+ * Returns GZ_OK, or GZ_E_INVALID for an unknown key or a value out of range (nothing is changed then). */
+int  gz_debug_set(gz_ctx *ctx, const char *key, int64_t value);
+
 /* ---- batch decode ------------------------------------------------------------------------
  * gz_decoder_snapshot: build the id -> word map from the tables loaded so far, the way the reference builds
  *   `decoder` ONCE in __init__ (tokenize.py:40: {v: k for k, v in encoder.items()} -- on an id collision the last

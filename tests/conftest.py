@@ -24,6 +24,11 @@ def pytest_configure(config):
         d = tempfile.mkdtemp(prefix="gz_table_cache_")
         os.environ["GZ_TABLE_CACHE"] = d
         atexit.register(shutil.rmtree, d, True)
+    # switches of the library a parent test asked for (GZ_TEST_SWITCHES="small=0,scan_multi=0": gz_switches.py -> gz_debug_set): set
+    # as process-wide defaults before any context exists.  The library itself reads no switch from the environment.
+    if os.environ.get("GZ_TEST_SWITCHES"):
+        import gz_switches
+        gz_switches.apply()
 
 
 def read_jsonl(name):

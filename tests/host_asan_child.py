@@ -26,6 +26,10 @@ L.gz_host_tables_vocab_entry.argtypes = [vp, i64, C.POINTER(vp), C.POINTER(i32),
 L.gz_host_tables_merge_entry.argtypes = [vp, i64, C.POINTER(vp), C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]
 L.gz_host_tables_symbol.argtypes = [vp, i32, C.POINTER(vp), C.POINTER(i32)]
 L.gz_last_error.argtypes = [vp]; L.gz_last_error.restype = C.c_char_p
+L.gz_debug_set.argtypes = [vp, C.c_char_p, i64]
+sys.path.insert(0, ROOT)
+import gz_switches                                              # GZ_TEST_SWITCHES -> gz_debug_set(NULL, ...) of THIS library
+gz_switches.apply(lib=L)
 SPECIALS = ("<pad>", "<s>", "</s>", "<mask>", "<unk>")
 WIDTH = {0: 16, 1: 16, 2: 8, 3: 8, 4: 16, 5: 4, 6: 8, 7: 2, 8: 4, 9: 8}
 

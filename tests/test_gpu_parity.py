@@ -324,12 +324,12 @@ def test_csr_host_path_matches_dense(tok, sampler, tmp_path):
 
 
 def test_big_pipeline_on_small_inputs():
-    """Small dense single-text batches run in ONE fused launch (gz_small_kernel); GZ_SMALL=0 sends them through the
+    """Small dense single-text batches run in ONE fused launch (gz_small_kernel); the switch small = 0 sends them through the
     kernel pipeline instead.  The golden vectors and the small-input comparisons of this file run again that way in a
     child process, so that both forms stay pinned to the reference on the hostile small cases."""
-    # (GZ_SCAN_MULTI=0: the block-count scans go through the chained multi-workgroup kernel whatever the size -- large
+    # (scan_multi = 0: the block-count scans go through the chained multi-workgroup kernel whatever the size -- large
     # batches use it by default, here it also sees one-chunk and few-element inputs)
-    env = dict(os.environ, GZ_SMALL="0", GZ_SCAN_MULTI="0")
+    env = dict(os.environ, GZ_TEST_SWITCHES="small=0,scan_multi=0")
     _run_selection("big_pipeline_on_small_inputs", env,
                    "g1_cases or g3_random or g4_loader or cfg2_10k or cfg3_20k or noisy_corpus or long_and_huge or random_tables_fuzz or extreme_batch")
 
@@ -352,17 +352,16 @@ def test_index_assertions_on_a_poisoned_workspace():
     test_big_pipeline_on_small_inputs (round 4: one child of it aborted once, unexplained) plus the pair corpora: tiny batches, the
     load-time whole-word build with its many words of 17..32 symbols, random tables, words of up to 3 000 symbols -- all through
     the kernel pipeline, the chained scan on every size."""
-    env = dict(os.environ, GZ_LIBRARY=_diag_library(), GZ_SMALL="0", GZ_SCAN_MULTI="0", GZ_DIAG_POISON="1", GZ_BRK_SIDE="0",
-               GZ_TABLE_CACHE="off")
+    env = dict(os.environ, GZ_LIBRARY=_diag_library(), GZ_TEST_SWITCHES="small=0,scan_multi=0,diag_poison=1,brk_side=0", GZ_TABLE_CACHE="off")
     _run_selection("diag_index_assertions", env,
                    "g1_cases or g3_random or g4_loader or cfg2_10k or cfg3_20k or noisy_corpus or noisy_pairs or long_and_huge or random_tables_fuzz or extreme_batch or not_utf8")
 
 
 def test_dense_hash_tables():
     """The long-key whole-word table (words of 17..32 bytes, linear probing) is built at 1/16 load, so its continue-probing
-    branches almost never run on the default build.  GZ_TAB_SLACK=2 builds it at half load: the golden batches, the 20 k-document digests, the noisy corpora (single and
+    branches almost never run on the default build.  The switch tab_slack = 2 builds it at half load: the golden batches, the 20 k-document digests, the noisy corpora (single and
     pairs), long words and the small-kernel shapes run again that way in a child process."""
-    env = dict(os.environ, GZ_TAB_SLACK="2")
+    env = dict(os.environ, GZ_TEST_SWITCHES="tab_slack=2")
     _run_selection("dense_hash_tables", env,
                    "g1_cases or g3_random or cfg3_20k or noisy_corpus or noisy_pairs or long_and_huge or small_kernel_shapes or random_tables_fuzz")
 
@@ -370,25 +369,25 @@ def test_dense_hash_tables():
 def test_perfect_hash_overflow_buckets_on_the_gpu():
     """The perfectly hashed tables never need an overflow bucket on real files, so the kernels' "this bucket could not be
     placed: probe on" branches (and the merge kernel's OVF instantiation) never run on the default build.
-    GZ_PH_FORCE_OVERFLOW=3 makes the builder refuse every third bucket -- several thousand keys of both tables then sit in
+    The switch ph_force_overflow = 3 makes the builder refuse every third bucket -- several thousand keys of both tables then sit in
     overflow buckets: the golden batches, the 20 k-document digests, the noisy corpora, long words and random tables run
     again that way in a child process (table cache off, so that the tables are really rebuilt)."""
-    env = dict(os.environ, GZ_PH_FORCE_OVERFLOW="3", GZ_TABLE_CACHE="off")
+    env = dict(os.environ, GZ_TEST_SWITCHES="ph_force_overflow=3", GZ_TABLE_CACHE="off")
     _run_selection("overflow_buckets", env,
                    "g1_cases or g3_random or cfg3_20k or noisy_corpus or noisy_pairs or long_and_huge or random_tables_fuzz")
 
 
-@pytest.mark.parametrize("switches", [{"GZ_SIDE": "0", "GZ_BRK_SIDE": "0"}, {"GZ_ASSEMBLE": "2"}, {"GZ_ASSEMBLE": "1"},
-                                      {"GZ_M2_SPLIT_MIN": "1", "GZ_M2_SPLIT_ALWAYS": "1"}],
+@pytest.mark.parametrize("switches", [{"side": 0, "brk_side": 0}, {"assemble": 2}, {"assemble": 1},
+                                      {"m2_split_min": 1, "m2_split_always": 1}],
                          ids=["one_stream", "lds_row_kernel", "scatter_row_kernel", "two_merge_instances"])
 def test_alternative_kernels_stay_exact(switches):
-    """Schedules and kernels the library keeps beside the default ones: everything on one stream (GZ_SIDE=0 / GZ_BRK_SIDE=0), and
-    the pair-mode / ragged row writers run on dense single texts (GZ_ASSEMBLE=2: whole rows through LDS, the pair-mode kernel; 1:
+    """Schedules and kernels the library keeps beside the default ones: everything on one stream (side = 0, brk_side = 0), and
+    the pair-mode / ragged row writers run on dense single texts (assemble = 2: whole rows through LDS, the pair-mode kernel; 1:
     the scatter kernel of the ragged layouts); the merge kernel's two instances (words of up to 8 / up to 16 symbols, gz_hot.inc)
     sharing EVERY batch, however small and with the whole-word tables on -- by default they only do when the tables are off and
     the misses are many.  Each runs the golden batches, the 20 k-document digests, the noisy corpora, bytes that are not UTF-8
     and the long words in a child process, small batches through the pipeline."""
-    env = dict(os.environ, GZ_SMALL="0", **switches)
+    env = dict(os.environ, GZ_TEST_SWITCHES=",".join(["small=0"] + ["%s=%d" % kv for kv in sorted(switches.items())]))
     _run_selection("alternative_kernels_" + "_".join("%s%s" % kv for kv in sorted(switches.items())), env,
                    "g1_cases or g3_random_batched or cfg3_20k or noisy_corpus or long_and_huge or extreme_batch or not_utf8")
 
@@ -396,10 +395,10 @@ def test_alternative_kernels_stay_exact(switches):
 def test_far_word_records_on_small_batches():
     """A merged word's record has two forms (gz_pipeline.inc, W_NEAR): "near" -- count and place of its tokens in the record
     itself, for the first 2^25 places of the compact token area -- and "far" (count in the record, place in waux).  Batches
-    below some 10 M merged words only ever produce near records: GZ_NEAR_LIMIT=300 gives the far form to every word placed
+    below some 10 M merged words only ever produce near records: the switch near_limit = 300 gives the far form to every word placed
     from 300 on, so that the golden batches, the 20 k-document digests, the noisy corpora, the word-count output and the long
     words see BOTH forms side by side, in a child process with the small batches sent through the kernel pipeline."""
-    env = dict(os.environ, GZ_NEAR_LIMIT="300", GZ_SMALL="0")
+    env = dict(os.environ, GZ_TEST_SWITCHES="near_limit=300,small=0")
     _run_selection("far_word_records", env,
                    "g1_cases or g3_random or cfg3_20k or noisy_corpus or noisy_pairs or long_and_huge or csr_host_path or large_noisy or extreme_batch")
 
@@ -944,9 +943,11 @@ import numpy as np
 root = %r
 sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "genz-tokenize_amd"))
 import corpus
+import gz_switches
 from genz_tokenize import Tokenize, _native
+assert gz_switches.apply() == [("scan_multi", 0)]
 tok = Tokenize(); tok._sync_tables(); ctx = tok._ctx
-text, offs, L = corpus.config_corpus(3, n_docs=60000)           # (GZ_SCAN_MULTI=0: every block-count scan is the chained kernel)
+text, offs, L = corpus.config_corpus(3, n_docs=60000)           # (scan_multi = 0: every block-count scan is the chained kernel)
 offs = np.ascontiguousarray(offs, dtype=np.int64)
 toks, nr = ctx.encode_csr(text, offs, L, 16)                    # healthy first
 n_tok = len(toks)
@@ -974,7 +975,7 @@ toks2, _ = ctx.encode_csr(text, offs, L, 16)                    # and the contex
 assert len(toks2) == n_tok and np.array_equal(toks2, toks)
 print("ok")
 """ % root
-    env = dict(os.environ, GZ_LIBRARY=os.path.join(root, "build_ab", "libgz_diag.so"), GZ_SCAN_MULTI="0")
+    env = dict(os.environ, GZ_LIBRARY=os.path.join(root, "build_ab", "libgz_diag.so"), GZ_TEST_SWITCHES="scan_multi=0")
     r = _run_child([sys.executable, "-c", child], "scan_time_out", env=env)
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), r.report
 
@@ -1233,7 +1234,7 @@ def test_preprocess_fused_and_filter_by_filter_paths():
     skipped when a look at the bytes shows they cannot apply); longer ones go filter by filter through HBM.  Both against the
     oracle around the size limit -- 4 094 ... 4 098 bytes with tags, URLs, combining marks, emoji and whitespace runs at the
     very end -- mixed in one batch; and the reference-generated G7 rows + the long-document comparison once more with
-    GZ_PP_FUSED=0 (everything filter by filter) in a child process."""
+    pp_fused = 0 (everything filter by filter) in a child process."""
     import random
     import subprocess
     import sys
@@ -1256,7 +1257,7 @@ def test_preprocess_fused_and_filter_by_filter_paths():
         got = P.preprocess_batch(docs, ops)
         for d, g in zip(docs, got):
             assert g == O.preprocess(d, ops), (ops, len(d.encode("utf-8")), d[-40:])
-    env = dict(os.environ, GZ_PP_FUSED="0")
+    env = dict(os.environ, GZ_TEST_SWITCHES="pp_fused=0")
     _run_selection("preprocess_filter_by_filter", env, "g7_preprocess or preprocess_long_documents")
 
 
@@ -1422,6 +1423,54 @@ def test_extreme_batch_shapes(tok, sampler):
     assert np.array_equal(out["input_ids"], np.tile(np.array([sp[1], sp[2]] + [sp[0]] * 6, dtype=np.int32), (5000, 1)))
     out = tok.encode_batch(empties, empties, max_len=None)
     assert np.array_equal(np.diff(out["row_off"]), np.full(5000, 4))
+
+
+def test_rows_apart_chain_is_exact(sampler):
+    """Option rows_apart (gz_debug_set): the row kernel of a dense device call runs on a stream of its own, beside the text side
+    of the NEXT call, the calls alternating between two workspace slots.  A chain of calls of different sizes -- each slot used
+    several times, a call of another kind (ragged rows) in the middle, the exchange step's compaction behind it -- must give
+    what each call gives alone; the chain's timed durations add up to no more than its span."""
+    from genz_tokenize import Tokenize, _native
+    tok = Tokenize(); tok._sync_tables()
+    ctx = tok._ctx
+    flags = _native.GZ_PADDING | _native.GZ_TRUNCATION | _native.GZ_TIMING
+    jobs = []
+    for seed, n, L in ((1, 30000, 64), (2, 200000, 48), (3, 50, 256), (4, 120000, 128), (5, 1, 16), (6, 60000, 256), (7, 90000, 1024), (8, 3000, 8)):
+        text, offs, _ = corpus.config_corpus(3, n_docs=n, seed=300 + seed, sampler=sampler)
+        offs = np.ascontiguousarray(offs, dtype=np.int64)
+        want = tok.encode_packed(text, offs, max_len=L)
+        d_t = ctx.alloc(len(text) + 64); ctx.h2d(d_t, text)
+        d_o = ctx.alloc(8 * (n + 1)); ctx.h2d(d_o, offs)
+        d_i, d_m, d_r = ctx.alloc(4 * n * L), ctx.alloc(4 * n * L), ctx.alloc(4 * n)
+        jobs.append((text, offs, n, L, want, d_t, d_o, d_i, d_m, d_r))
+    ctx.sync()
+    _native.debug_set("rows_apart", 1, ctx)
+    for rnd in range(2):
+        for _, offs, n, L, _, d_t, d_o, d_i, d_m, d_r in jobs:
+            ctx.encode_device(d_t, d_o, 0, 0, n, L, flags, n * L, d_i, d_m, d_n_real=d_r, h_text_off=offs)      # no sync in between
+        if rnd == 0:
+            # a ragged call of the ordinary kind between two chains: it waits for every row kernel still in flight
+            text, offs = jobs[0][0], jobs[0][1]
+            rag = tok.encode_packed(text, offs, max_len=None)
+            assert np.array_equal(np.minimum(np.diff(rag["row_off"]), jobs[0][3]), jobs[0][4]["n_real"])
+    hist = ctx.timing_history(64)
+    assert len(hist) == len(jobs) and all(t > 0 for t in hist)
+    for _, offs, n, L, want, d_t, d_o, d_i, d_m, d_r in jobs:
+        ids = np.empty((n, L), np.int32); mask = np.empty((n, L), np.int32); nr = np.empty(n, np.int32)
+        ctx.d2h(ids, d_i); ctx.d2h(mask, d_m); ctx.d2h(nr, d_r)
+        assert np.array_equal(ids, want["input_ids"]) and np.array_equal(mask, want["attention_mask"])
+        assert np.array_equal(nr, want["n_real"])
+    # the exchange step's compaction takes its place behind the LAST call's row kernel
+    _, offs, n, L, want, d_t, d_o, d_i, d_m, d_r = jobs[-3]
+    ctx.encode_device(d_t, d_o, 0, 0, n, L, flags, n * L, d_i, d_m, d_n_real=d_r, h_text_off=offs)
+    d_blk = ctx.alloc(4 * (n + n * L))
+    total = ctx.compact_block(d_i, d_r, n, L, d_blk, bits=16)
+    assert total == int(want["n_real"].sum())
+    ctx.sync()
+    for job in jobs:
+        for p in job[5:]:
+            ctx.free(p)
+    ctx.free(d_blk)
 
 
 def test_chained_device_calls(tok, sampler):

@@ -95,9 +95,9 @@ def test_perfect_hash_pair_table_is_complete_dense_and_refuses_non_members(bundl
 
 
 def test_perfect_hash_overflow_buckets_and_alias_flag():
-    """Forced overflow buckets (GZ_PH_FORCE_OVERFLOW: every third bucket is refused by the builder, as a table it cannot
-    place would be) and two merge lines that spell the same string (alias flag: the merged symbol is the smaller rank's),
-    in a child process (the switch is read once)."""
+    """Forced overflow buckets (the builder switch ph_force_overflow = 3 -- gz_debug_set: every third bucket is refused, as a table
+    the builder cannot place would be) and two merge lines that spell the same string (alias flag: the merged symbol is the
+    smaller rank's), in a child process (the switch is process-wide)."""
     import os
     import subprocess
     import sys
@@ -110,6 +110,12 @@ for p in (root, os.path.join(root, "tests"), os.path.join(root, "oracle"), os.pa
 from genz_tokenize import _native
 from table_sim import TableSim
 import gz_oracle as O
+_native.debug_set("ph_force_overflow", 3)
+for bad in (("no_such_key", 1), ("ph_force_overflow", -1), ("tab_slack", 1), ("small", 2)):      # unknown key / out of range: refused
+    try:
+        _native.debug_set(*bad); raise SystemExit("gz_debug_set accepted %%r" %% (bad,))
+    except ValueError:
+        pass
 data = os.path.join(root, "genz-tokenize_amd", "genz_tokenize", "data")
 v = open(data + "/vocab.txt", "rb").read()
 b = open(data + "/bpe.codes", "rb").read()
@@ -130,8 +136,7 @@ assert y["abc"] == 2 and s2.probe8(y["a"], y["bc"], False) == (2, 0) and s2.prob
 assert int(s2.merges[3][2]) == 2
 print("ok")
 """ % root
-    env = dict(os.environ, GZ_PH_FORCE_OVERFLOW="3")
-    r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=600, env=env)
+    r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=600, env=dict(os.environ))
     assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-1500:], r.stderr[-3000:])
 
 
@@ -184,8 +189,8 @@ def test_host_builder_under_sanitizers():
         pytest.skip("libasan.so not found next to gcc")
     env = dict(os.environ, LD_PRELOAD=asan, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0:halt_on_error=1",
                UBSAN_OPTIONS="print_stacktrace=1:halt_on_error=1")
-    for slack in ("16", "2"):                   # the pair hash at its default load and at half load (long probe chains)
-        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "host_asan_child.py")], env=dict(env, GZ_TAB_SLACK=slack),
+    for force in ("0", "3"):                    # the perfect hash as the builder places it, and with every third bucket forced into overflow
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "host_asan_child.py")], env=dict(env, GZ_TEST_SWITCHES="ph_force_overflow=" + force),
                            capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
         assert "asan child ok" in r.stdout
@@ -202,7 +207,7 @@ def test_host_builder_threads_under_tsan(tmp_path):
     csrc = os.path.join(ROOT, "genz-tokenize_amd", "csrc")
     exe = str(tmp_path / "host_tsan")
     c = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=thread", "-DGZ_HOST_ONLY", "-I", csrc, "-I", os.path.join(ROOT, "include"),
-                        os.path.join(ROOT, "tests", "native", "host_tsan_main.cpp"), os.path.join(csrc, "gz_tables.cpp"), "-o", exe, "-lpthread"],
+                        os.path.join(ROOT, "tests", "native", "host_tsan_main.cpp"), os.path.join(csrc, "gz_tables.cpp"), os.path.join(csrc, "gz_host_api.cpp"), "-o", exe, "-lpthread"],
                        capture_output=True, text=True, timeout=600)
     if c.returncode != 0 and "tsan" in (c.stderr or "").lower() and "cannot find" in c.stderr:
         pytest.skip("libtsan is not installed")

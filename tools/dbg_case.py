@@ -2,6 +2,7 @@ import gzip, json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "genz-tokenize_amd"))
 from genz_tokenize import Tokenize
+sys.path.insert(0, ROOT); import gz_switches; gz_switches.apply()      # GZ_TEST_SWITCHES="key=value,..." -> gz_debug_set (the library reads no switch from the environment)
 tok = Tokenize()
 rows = [json.loads(l) for l in gzip.open(os.path.join(ROOT, "tests/golden/g3_random.jsonl.gz"), "rt")]
 bad = 0

@@ -11,6 +11,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "genz-tokenize_a
 import numpy as np
 import corpus
 from genz_tokenize import Tokenize, _native
+sys.path.insert(0, ROOT); import gz_switches; gz_switches.apply()      # GZ_TEST_SWITCHES="key=value,..." -> gz_debug_set (the library reads no switch from the environment)
 
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 v, b = corpus.custom_tables()

@@ -7,6 +7,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "genz-tokenize_a
 import numpy as np
 import corpus
 from genz_tokenize import Tokenize
+sys.path.insert(0, ROOT); import gz_switches; gz_switches.apply()      # GZ_TEST_SWITCHES="key=value,..." -> gz_debug_set (the library reads no switch from the environment)
 
 n_docs = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 tok = Tokenize(); tok._sync_tables(); ctx = tok._ctx

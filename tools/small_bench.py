@@ -3,6 +3,7 @@ ROOT = os.getcwd()
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "genz-tokenize_amd"))
 import numpy as np, corpus
 from genz_tokenize import Tokenize, _native
+sys.path.insert(0, ROOT); import gz_switches; gz_switches.apply()      # GZ_TEST_SWITCHES="key=value,..." -> gz_debug_set (the library reads no switch from the environment)
 tok = Tokenize(); tok._sync_tables(); ctx = tok._ctx
 t2, o2, L2 = corpus.config_corpus(2)
 t2 = np.ascontiguousarray(t2); o2 = np.ascontiguousarray(o2, dtype=np.int64)
@@ -17,7 +18,7 @@ for k in range(23):
     ctx.encode_device(d_t, d_o, 0, 0, n, L2, flags, n * L2, d_i, d_m, d_n_real=d_r, h_text_off=o2)
     ctx.sync()
     res.append(((time.perf_counter() - a) * 1e3, ctx.timing()[0]))
-print("configs[1] %s: wall ms median %.4f  kernels ms median %.4f" % (os.environ.get("GZ_SMALL", "1"), np.median([x for x, _ in res[3:]]), np.median([y for _, y in res[3:]])))
+print("configs[1] %s: wall ms median %.4f  kernels ms median %.4f" % (os.environ.get("GZ_TEST_SWITCHES", "-"), np.median([x for x, _ in res[3:]]), np.median([y for _, y in res[3:]])))
 
 if os.environ.get("SMALL_ONLY"):
     sys.exit(0)

@@ -6,6 +6,7 @@ ROOT = os.getcwd()
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "genz-tokenize_amd"))
 import numpy as np, corpus
 from genz_tokenize import Tokenize, _native
+sys.path.insert(0, ROOT); import gz_switches; gz_switches.apply()      # GZ_TEST_SWITCHES="key=value,..." -> gz_debug_set (the library reads no switch from the environment)
 tok = Tokenize(); tok._sync_tables(); ctx = tok._ctx
 t2, o2, L2 = corpus.config_corpus(2)
 t2 = np.ascontiguousarray(t2); o2 = np.ascontiguousarray(o2, dtype=np.int64)

@@ -10,6 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "genz-tokenize_amd"))
 t0 = time.perf_counter()
 from genz_tokenize import Tokenize  # noqa: E402
+sys.path.insert(0, ROOT); import gz_switches; gz_switches.apply()      # GZ_TEST_SWITCHES="key=value,..." -> gz_debug_set (the library reads no switch from the environment)
 t1 = time.perf_counter()
 d = os.path.join(ROOT, "genz-tokenize_amd", "genz_tokenize", "data")
 

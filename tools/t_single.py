@@ -4,6 +4,7 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "genz-tokenize_amd"))
 from genz_tokenize import Tokenize
+sys.path.insert(0, ROOT); import gz_switches; gz_switches.apply()      # GZ_TEST_SWITCHES="key=value,..." -> gz_debug_set (the library reads no switch from the environment)
 tok = Tokenize()
 cases = [("sinh_viên công_nghệ", "hello", 10), ("xin chào việt nam " * 8, None, 64), ("xin chào việt nam " * 60, None, 256)]
 for a, b, L in cases:
