@@ -1425,11 +1425,13 @@ def test_extreme_batch_shapes(tok, sampler):
     assert np.array_equal(np.diff(out["row_off"]), np.full(5000, 4))
 
 
-def test_rows_apart_chain_is_exact(sampler):
+@pytest.mark.parametrize("mode", [{"rows_apart": 1}, {"rows_apart": 2}, {"rows_apart": 2, "rows_wgs": 96, "hot_wgs": 256}, {"rows_apart": 3}],
+                         ids=["beside_next_call", "held_until_next_classification", "held_small_grids", "held_until_next_word_kernel"])
+def test_rows_apart_chain_is_exact(sampler, mode):
     """Option rows_apart (gz_debug_set): the row kernel of a dense device call runs on a stream of its own, beside the text side
-    of the NEXT call, the calls alternating between two workspace slots.  A chain of calls of different sizes -- each slot used
-    several times, a call of another kind (ragged rows) in the middle, the exchange step's compaction behind it -- must give
-    what each call gives alone; the chain's timed durations add up to no more than its span."""
+    of the NEXT call, the calls alternating between two workspace slots (2: held back until that call's classification is done;
+    rows_wgs: a small grid that walks the rounds).  A chain of calls of different sizes -- each slot used several times, a call of
+    another kind (ragged rows) in the middle, the exchange step's compaction behind it -- must give what each call gives alone."""
     from genz_tokenize import Tokenize, _native
     tok = Tokenize(); tok._sync_tables()
     ctx = tok._ctx
@@ -1444,7 +1446,8 @@ def test_rows_apart_chain_is_exact(sampler):
         d_i, d_m, d_r = ctx.alloc(4 * n * L), ctx.alloc(4 * n * L), ctx.alloc(4 * n)
         jobs.append((text, offs, n, L, want, d_t, d_o, d_i, d_m, d_r))
     ctx.sync()
-    _native.debug_set("rows_apart", 1, ctx)
+    for k, v in mode.items():
+        _native.debug_set(k, v, ctx)
     for rnd in range(2):
         for _, offs, n, L, _, d_t, d_o, d_i, d_m, d_r in jobs:
             ctx.encode_device(d_t, d_o, 0, 0, n, L, flags, n * L, d_i, d_m, d_n_real=d_r, h_text_off=offs)      # no sync in between
@@ -1454,7 +1457,7 @@ def test_rows_apart_chain_is_exact(sampler):
             rag = tok.encode_packed(text, offs, max_len=None)
             assert np.array_equal(np.minimum(np.diff(rag["row_off"]), jobs[0][3]), jobs[0][4]["n_real"])
     hist = ctx.timing_history(64)
-    assert len(hist) == len(jobs) and all(t > 0 for t in hist)
+    assert len(hist) == 2 * len(jobs) and all(t > 0 for t in hist)
     for _, offs, n, L, want, d_t, d_o, d_i, d_m, d_r in jobs:
         ids = np.empty((n, L), np.int32); mask = np.empty((n, L), np.int32); nr = np.empty(n, np.int32)
         ctx.d2h(ids, d_i); ctx.d2h(mask, d_m); ctx.d2h(nr, d_r)

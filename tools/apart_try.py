@@ -16,6 +16,7 @@ n_docs = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 launches = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 settings = sys.argv[4:] or ["-", "rows_apart=1", "rows_apart=1,hot_wgs=256"]
+gz_switches.apply()
 tok = Tokenize(); tok._sync_tables()
 c = tok._ctx
 seed = int(os.environ["SEED"]) if os.environ.get("SEED") else None
@@ -27,6 +28,8 @@ outs = [(c.alloc(4 * n * L), c.alloc(4 * n * L), c.alloc(4 * n)) for _ in range(
 flags = _native.GZ_PADDING | _native.GZ_TRUNCATION | _native.GZ_TIMING
 hoff = np.ascontiguousarray(offs, dtype=np.int64)
 DEFAULTS = {"rows_apart": 0, "hot_wgs": 0, "hot_miss_wgs": 0, "side": 1, "brk_side": 1}
+if any("rows_prio" in s for s in settings):
+    sys.exit("apart_try.py: rows_prio is read when a context makes its rows stream: pass it through GZ_TEST_SWITCHES (process-wide), one run per value")
 
 
 def run(setting):
