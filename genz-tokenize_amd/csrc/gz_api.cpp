@@ -98,7 +98,6 @@ struct gz_ctx {
         bool keep_words = false;
         int t_slot = 0;                // timing: the call's pair of events in the ring
         bool chained = false;          // enqueued behind a call that has not been synchronised (its scan flag is kept)
-        bool apart = false; int flip = 0;   // the row kernel on the rows stream; workspace slot of the call (option rows_apart)
         bool inputs_resident = false;  // the caller's device buffers are readable now (no copy of them is queued on the stream)
     } pend;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
@@ -119,19 +118,6 @@ struct gz_ctx {
     uint32_t lb_epoch = 0;               // call number of the chained scans (gz_scan32m_kernel)   // [slot][text]
     hipStream_t stream2 = nullptr;       // sub-batches alternate between the two streams
     hipStream_t side = nullptr;          // the wide-word kernels of a text run here, beside the merge kernel
-    // Option rows_apart: the row kernel of a dense single-text device call runs on a stream of its own; consecutive calls alternate
-    // between the two workspace slots, so the row kernel of call i (bound by its stores) runs beside the text side of call i + 1
-    // (bound by vector and LDS work) on the SAME compute units.  ev_text[slot]: the text side of the call that uses the slot is
-    // done; ev_rows[slot]: so is its row kernel (the slot's word records, token area and first-word indices may be overwritten).
-    hipStream_t rows_stream = nullptr;
-    hipEvent_t ev_text[2] = {nullptr, nullptr}, ev_rows[2] = {nullptr, nullptr}, ev_cls[2] = {nullptr, nullptr}, ev_wrd[2] = {nullptr, nullptr};
-    bool rows_rec[2] = {false, false};
-    // rows_apart = 2: the row kernel of a call is not launched with the call but when the NEXT call has enqueued its classification
-    // (it then waits for that too: it runs beside the next call's word / merge kernels), or when anything else needs it
-    // (synchronisation, an exchange step, a call of another kind)
-    struct HeldRows { bool have = false; GzAsmArgs A{}; int flip = 0; bool timing = false; int t_slot = 0; uint64_t seq = 0; } held;
-    uint64_t apart_seq = 0;
-    bool rows_used = false;
     bool flags_lazy = false;       // the device flags of the pending chain have not been copied to h_flags yet (sync_locked does it)
     bool caller_buffers = false;   // set by the device entry points around encode_device_locked: text / offsets are the caller's
                                    // own device buffers (readable now), not staging copies queued on the stream
@@ -237,43 +223,12 @@ static int need_side_streams(gz_ctx* c, bool second)
     return GZ_OK;
 }
 
-// the row kernel of a rows_apart call, on the rows stream: behind the call's own text side, and (ev_after, may be null) behind
-// the next call's classification
-int launch_rows_apart(gz_ctx* c, const GzAsmArgs& A, int flip, bool timing, int t_slot, uint64_t seq, hipEvent_t ev_after)
-{
-    const GzDeviceTables* T = (const GzDeviceTables*)c->t_struct.p;
-    HIPCHK(c, hipStreamWaitEvent(c->rows_stream, c->ev_text[flip], 0));
-    if (ev_after) HIPCHK(c, hipStreamWaitEvent(c->rows_stream, ev_after, 0));
-    gz_launch_assemble(c->opt, T, A, c->rows_stream);
-    HIPCHK(c, hipEventRecord(c->ev_rows[flip], c->rows_stream));
-    c->rows_rec[flip] = true; c->rows_used = true;
-    if (timing) HIPCHK(c, hipEventRecord(c->ring[t_slot][1], c->rows_stream));
-    HIPCHK(c, hipEventRecord(c->ev_tok[seq & 3], c->rows_stream));
-    return GZ_OK;
-}
-int flush_held_rows(gz_ctx* c, hipEvent_t ev_after = nullptr)
-{
-    if (!c->held.have) return GZ_OK;
-    c->held.have = false;
-    return launch_rows_apart(c, c->held.A, c->held.flip, c->held.timing, c->held.t_slot, c->held.seq, ev_after);
-}
-
 int enqueue(gz_ctx* c)
 {
     gz_ctx::Pending& p = c->pend;
     hipStream_t s = c->stream;
     const GzDeviceTables* T = (const GzDeviceTables*)c->t_struct.p;
     if (c->x_used) HIPCHK(c, hipStreamWaitEvent(s, c->ev_x, 0));    // output buffers may still be read by an exchange step
-    if (!p.apart) { int rh = flush_held_rows(c); if (rh) return rh; }
-    if (c->rows_used) {
-        // row kernels of earlier calls may still run on the rows stream: a call of the same kind waits for the one that used ITS
-        // workspace slot (two calls back); any other call waits for all of them
-        // (rows_apart = 3: the wait sits inside the call, before its word kernel -- the classification writes nothing the row kernel
-        // of two calls back reads)
-        if (p.apart) { if (c->rows_rec[p.flip] && c->opt.rows_apart < 3) HIPCHK(c, hipStreamWaitEvent(s, c->ev_rows[p.flip], 0)); }
-        else for (int i = 0; i < 2; ++i) if (c->rows_rec[i]) HIPCHK(c, hipStreamWaitEvent(s, c->ev_rows[i], 0));
-    }
-    if (p.apart && c->x_used) HIPCHK(c, hipStreamWaitEvent(c->rows_stream, c->ev_x, 0));
     const bool no_flags = p.small && !p.ragged;                 // (a dense one-launch call raises no flag)
     // [0] scan time-out, [1] capacity error, [3] a word needs the wide / long kernels.  Calls chained without a host
     // synchronisation keep [0]: it is only cleared when a chain starts, so a time-out in ANY call of the chain is still
@@ -302,24 +257,13 @@ int enqueue(gz_ctx* c)
     for (size_t k = 0; k < p.subs.size(); ++k) {
         hipStream_t sk = (k & 1) ? c->stream2 : s;
         const GzAsmArgs& S = p.subs[k];
-        const int e = (int)((k + (size_t)p.flip) & 1);           // the workspace slot, and its events
         for (int tx = 0; tx < S.n_texts; ++tx)
-            gz_launch_pipeline_text(c->opt, T, c->dev, S.X[tx], S.n_docs, p.use_words, (int32_t*)c->w_flags.p + 3, sk, c->side, c->ev_sf0[e][tx], c->ev_sf[e][tx], c->ev_sj[e][tx],
-                                    p.inputs_resident ? c->ev_sb[e][tx] : nullptr, p.apart ? c->ev_cls[p.flip] : nullptr,
-                                    (p.apart && c->opt.rows_apart >= 3 && c->rows_rec[p.flip]) ? c->ev_rows[p.flip] : nullptr,
-                                    (p.apart && c->opt.rows_apart >= 3) ? c->ev_wrd[p.flip] : nullptr);
-        if (p.apart) {
-            // the row kernel of the call BEFORE, if it was held back: now, behind this call's classification
-            { int rh = flush_held_rows(c, c->opt.rows_apart >= 3 ? c->ev_wrd[p.flip] : c->ev_cls[p.flip]); if (rh) return rh; }
-            HIPCHK(c, hipEventRecord(c->ev_text[p.flip], s));
-            const int t_slot = p.timing ? (int)(c->ring_n % gz_ctx::RING) : 0;
-            if (c->opt.rows_apart >= 2) {
-                c->held.have = true; c->held.A = S; c->held.flip = p.flip; c->held.timing = p.timing; c->held.t_slot = t_slot; c->held.seq = c->enc_seq;
-            } else { int rh = launch_rows_apart(c, S, p.flip, p.timing, t_slot, c->enc_seq, nullptr); if (rh) return rh; }
-        } else gz_launch_assemble(c->opt, T, S, sk);
+            gz_launch_pipeline_text(c->opt, T, c->dev, S.X[tx], S.n_docs, p.use_words, (int32_t*)c->w_flags.p + 3, sk, c->side, c->ev_sf0[k & 1][tx], c->ev_sf[k & 1][tx], c->ev_sj[k & 1][tx],
+                                    p.inputs_resident ? c->ev_sb[k & 1][tx] : nullptr);
+        gz_launch_assemble(c->opt, T, S, sk);
     }
     if (two) { HIPCHK(c, hipEventRecord(c->ev_join, c->stream2)); HIPCHK(c, hipStreamWaitEvent(s, c->ev_join, 0)); }
-    if (p.timing) { p.t_slot = (int)(c->ring_n % gz_ctx::RING); if (!p.apart) HIPCHK(c, hipEventRecord(c->ring[p.t_slot][1], s)); c->ring_n++; }      // (rows_apart: recorded behind the row kernel)
+    if (p.timing) { p.t_slot = (int)(c->ring_n % gz_ctx::RING); HIPCHK(c, hipEventRecord(c->ring[p.t_slot][1], s)); c->ring_n++; }
     if (p.ragged) {
         gz_launch_rowscan(p.F, (int64_t*)c->w_rowlen.p, s);
         gz_launch_finalize(c->dev, p.F, s);
@@ -330,7 +274,7 @@ int enqueue(gz_ctx* c)
     if (lazy_flags) c->flags_lazy = true;
     else if (!no_flags) { HIPCHK(c, hipMemcpyAsync(c->h_flags, c->w_flags.p, 8, hipMemcpyDeviceToHost, s)); c->flags_lazy = false; }
     else if (!p.chained) c->h_flags[0] = c->h_flags[1] = 0;
-    if (!p.apart) HIPCHK(c, hipEventRecord(c->ev_tok[c->enc_seq & 3], s));      // (rows_apart: recorded behind the row kernel)
+    HIPCHK(c, hipEventRecord(c->ev_tok[c->enc_seq & 3], s));
     c->enc_seq++;
     HIPCHK(c, hipGetLastError());
     return GZ_OK;
@@ -341,7 +285,6 @@ int enqueue(gz_ctx* c)
 int x_begin(gz_ctx* c)
 {
     if (!c->xstream) HIPCHK(c, hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));      // (a stream costs ~ 2.5 ms to create: made when first needed)
-    { int rh = flush_held_rows(c); if (rh) return rh; }         // (an exchange step waits for a call's rows: a held-back row kernel goes now)
     if (c->enc_seq > (uint64_t)c->x_back) HIPCHK(c, hipStreamWaitEvent(c->xstream, c->ev_tok[(c->enc_seq - 1 - (uint64_t)c->x_back) & 3], 0));
     return GZ_OK;
 }
@@ -358,13 +301,11 @@ extern "C" int gz_diag_check(unsigned int* out8, int clear);      // gz_hot.inc:
 
 int sync_locked(gz_ctx* c)
 {
-    { int rh = flush_held_rows(c); if (rh) return rh; }
     if (c->flags_lazy) {                                         // the flags of a chain of dense calls: copied once, now
         c->flags_lazy = false;
         HIPCHK(c, hipMemcpyAsync(c->h_flags, c->w_flags.p, 8, hipMemcpyDeviceToHost, c->stream));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->rows_used) { HIPCHK(c, hipStreamSynchronize(c->rows_stream)); c->rows_used = false; c->rows_rec[0] = c->rows_rec[1] = false; }
     if (c->x_used) HIPCHK(c, hipStreamSynchronize(c->xstream));
 #ifdef GZ_DIAG
     {
@@ -593,17 +534,6 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
             }
         }
     }
-    // (rows_apart: dense single texts from the caller's own device buffers, with host offsets -- the calls that can be chained)
-    p.apart = c->opt.rows_apart && nsub == 1 && dense && !is_pair && !p.keep_words && c->caller_buffers && h_text_off && c->opt.assemble >= 3 &&
-              max_len >= 4 && (max_len & 3) == 0 && max_len <= 1024;
-    if (p.apart && !c->rows_stream) {
-        int least = 0, greatest = 0;
-        if (c->opt.rows_prio && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess && least != greatest)
-            HIPCHK(c, hipStreamCreateWithPriority(&c->rows_stream, hipStreamNonBlocking, least));
-        else HIPCHK(c, hipStreamCreateWithFlags(&c->rows_stream, hipStreamNonBlocking));
-        for (int i = 0; i < 2; ++i) { HIPCHK(c, hipEventCreateWithFlags(&c->ev_text[i], hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_rows[i], hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_cls[i], hipEventDisableTiming)); HIPCHK(c, hipEventCreateWithFlags(&c->ev_wrd[i], hipEventDisableTiming)); }
-    }
-    p.flip = p.apart ? (int)(c->apart_seq++ & 1) : 0;
     p.subs.resize((size_t)nsub);
     for (int k = 0; k < nsub; ++k) {
         const int64_t lo = (int64_t)k * n_docs / nsub, hi = (int64_t)(k + 1) * n_docs / nsub;
@@ -616,7 +546,7 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
         S2.docs_per_wave = docs_per_wave;
         for (int tx = 0; tx < S2.n_texts; ++tx) {
             const int64_t* cut = tx ? cutB : cutA;
-            int rc2 = setup_text(c, c->tw[(k + p.flip) & 1][tx], c->w_tiny[(k + p.flip) & 7][tx], (tx ? pair : text) + cut[k], (tx ? pair_off : text_off) + lo,
+            int rc2 = setup_text(c, c->tw[k & 1][tx], c->w_tiny[k & 7][tx], (tx ? pair : text) + cut[k], (tx ? pair_off : text_off) + lo,
                                  cut[k + 1] - cut[k], S2.n_docs, c->stream, S2.X[tx]);
             if (rc2) return rc2;
         }
@@ -880,8 +810,6 @@ void gz_destroy(gz_ctx* c)
     if (c->ev_x) hipEventDestroy(c->ev_x);
     if (c->xstream) hipStreamDestroy(c->xstream);
     if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
-    if (c->rows_stream) { hipStreamSynchronize(c->rows_stream); hipStreamDestroy(c->rows_stream); }
-    for (int i = 0; i < 2; ++i) { if (c->ev_text[i]) hipEventDestroy(c->ev_text[i]); if (c->ev_rows[i]) hipEventDestroy(c->ev_rows[i]); if (c->ev_cls[i]) hipEventDestroy(c->ev_cls[i]); if (c->ev_wrd[i]) hipEventDestroy(c->ev_wrd[i]); }
     for (auto& a : c->ev_sf0) for (auto& e : a) if (e) hipEventDestroy(e);
     for (auto& a : c->ev_sb) for (auto& e : a) if (e) hipEventDestroy(e);
     for (auto& a : c->ev_sf) for (auto& e : a) if (e) hipEventDestroy(e);
@@ -1566,13 +1494,6 @@ int gz_timing_history(gz_ctx* c, double* out_ms, int32_t max, int32_t* n_out)
         const uint64_t k = c->ring_n - (uint64_t)n + (uint64_t)i;
         float ms = 0;
         HIPCHK(c, hipEventElapsedTime(&ms, c->ring[k % gz_ctx::RING][0], c->ring[k % gz_ctx::RING][1]));
-        // a call whose kernels began before the call before it had ended (rows_apart: its text side runs beside that call's row
-        // kernel) is charged from that call's END: the durations of a chain then add up to the chain's span, never to more
-        if (i > 0) {
-            float since_prev = 0;
-            HIPCHK(c, hipEventElapsedTime(&since_prev, c->ring[(k - 1) % gz_ctx::RING][1], c->ring[k % gz_ctx::RING][1]));
-            if (since_prev > 0 && since_prev < ms) ms = since_prev;
-        }
         out_ms[i] = ms;
     }
     *n_out = n;

@@ -68,12 +68,6 @@ struct GzOptions {
     int32_t hot_miss_wgs = 0;         // grid of gz_miss2_kernel (0: as above)
     int64_t m2_split_min = 65536;     // chunks of misses from which the merge kernel's two instances share a launch (0: never)
     int32_t m2_split_always = 0;      // 1: ... also with the whole-word tables on
-    int32_t rows_apart = 0;           // 1: the row kernel of a dense device call on a stream of its own, beside the NEXT call's text side (two workspace slots);
-                                      // 2: ... and held back until that call's classification is done: beside its word / merge kernels, not beside its memory-bound first pass
-                                      // 3: ... held back until that call's WORD kernel is done (beside its merge kernels and the classification after them);
-                                      //    a call's word kernel waits for the row kernel two calls back (same workspace slot) instead of the whole call
-    int32_t rows_wgs = 0;             // grid of gz_rows1_kernel (0: one round of documents per wave; n: n workgroups walk the rounds)
-    int32_t rows_prio = 0;            // ... 1: that stream at the LOWEST priority the device offers (read when the stream is made: the context's first such call)
     // ---- builder (process-wide: read when tables are built)
     int32_t tab_slack = GZ_TAB_SLACK; // long-key whole-word table: slots >= this x entries (2 .. 64)
     int32_t ph_force_overflow = 0;    // k > 0: the perfect-hash builder refuses every k-th bucket (overflow paths of the kernels)

@@ -81,11 +81,7 @@ void gz_launch_pipeline_text(const GzOptions& O, const GzDeviceTables* T_dev, co
                              int32_t* long_flag /* device int, zeroed by the caller */, hipStream_t s,
                              hipStream_t side = nullptr, hipEvent_t ev_fork0 = nullptr, hipEvent_t ev_fork = nullptr, hipEvent_t ev_join = nullptr,
                              hipEvent_t ev_brk = nullptr /* non-null: X.off is readable NOW (no copy of it is queued on s): the document-start
-                                                            bits are prepared on the side stream, under whatever s is still running */,
-                             hipEvent_t ev_classified = nullptr /* non-null: recorded on s behind the classification and its scan */,
-                             hipEvent_t ev_before_words = nullptr /* non-null: s waits for it before anything that writes the per-word arrays
-                                                                     (first-word indices, word records) */,
-                             hipEvent_t ev_words_done = nullptr /* non-null: recorded on s behind the word kernel */);
+                                                            bits are prepared on the side stream, under whatever s is still running */);
 void gz_launch_pick(const int64_t* off, const int64_t* off2, int64_t n_docs, int nsub, int64_t* out /* 2*(nsub+1) */, hipStream_t s);
 void gz_launch_row_offsets(const int32_t* n_real, int64_t n_rows, uint32_t* off, hipStream_t s);
 void gz_launch_compact(const int32_t* rows, const uint32_t* off, int64_t n_rows, int32_t row_len, void* out, int bits /* 32 | 16 */, hipStream_t s);

@@ -231,7 +231,6 @@ int64_t gz_limit(int which);
  *   near_limit (0..2^25; 2^25) token places below this get near records
  *   hot_wgs, hot_miss_wgs (0..65536; 0)   grids of the word / merge kernels (0: as many workgroups as the chip holds)
  *   m2_split_min (>= 0; 65536), m2_split_always (0..1; 0)   when the merge kernel's two instances share a launch
- *   rows_apart (0..1; 0)       the row kernel of a dense device call on its own stream beside the next call's text side
  *   builder: tab_slack (2..64; 16), ph_force_overflow (>= 0; 0), ph_hot_slots (0..8192; 1024), word_weights (0..2; 0)
  *   diagnostic build only: diag_poison (0..1), rows_dpw, rows_dbg, ablate
  * Returns GZ_OK, or GZ_E_INVALID for an unknown key or a value out of range (nothing is changed then). */

@@ -1425,57 +1425,6 @@ def test_extreme_batch_shapes(tok, sampler):
     assert np.array_equal(np.diff(out["row_off"]), np.full(5000, 4))
 
 
-@pytest.mark.parametrize("mode", [{"rows_apart": 1}, {"rows_apart": 2}, {"rows_apart": 2, "rows_wgs": 96, "hot_wgs": 256}, {"rows_apart": 3}],
-                         ids=["beside_next_call", "held_until_next_classification", "held_small_grids", "held_until_next_word_kernel"])
-def test_rows_apart_chain_is_exact(sampler, mode):
-    """Option rows_apart (gz_debug_set): the row kernel of a dense device call runs on a stream of its own, beside the text side
-    of the NEXT call, the calls alternating between two workspace slots (2: held back until that call's classification is done;
-    rows_wgs: a small grid that walks the rounds).  A chain of calls of different sizes -- each slot used several times, a call of
-    another kind (ragged rows) in the middle, the exchange step's compaction behind it -- must give what each call gives alone."""
-    from genz_tokenize import Tokenize, _native
-    tok = Tokenize(); tok._sync_tables()
-    ctx = tok._ctx
-    flags = _native.GZ_PADDING | _native.GZ_TRUNCATION | _native.GZ_TIMING
-    jobs = []
-    for seed, n, L in ((1, 30000, 64), (2, 200000, 48), (3, 50, 256), (4, 120000, 128), (5, 1, 16), (6, 60000, 256), (7, 90000, 1024), (8, 3000, 8)):
-        text, offs, _ = corpus.config_corpus(3, n_docs=n, seed=300 + seed, sampler=sampler)
-        offs = np.ascontiguousarray(offs, dtype=np.int64)
-        want = tok.encode_packed(text, offs, max_len=L)
-        d_t = ctx.alloc(len(text) + 64); ctx.h2d(d_t, text)
-        d_o = ctx.alloc(8 * (n + 1)); ctx.h2d(d_o, offs)
-        d_i, d_m, d_r = ctx.alloc(4 * n * L), ctx.alloc(4 * n * L), ctx.alloc(4 * n)
-        jobs.append((text, offs, n, L, want, d_t, d_o, d_i, d_m, d_r))
-    ctx.sync()
-    for k, v in mode.items():
-        _native.debug_set(k, v, ctx)
-    for rnd in range(2):
-        for _, offs, n, L, _, d_t, d_o, d_i, d_m, d_r in jobs:
-            ctx.encode_device(d_t, d_o, 0, 0, n, L, flags, n * L, d_i, d_m, d_n_real=d_r, h_text_off=offs)      # no sync in between
-        if rnd == 0:
-            # a ragged call of the ordinary kind between two chains: it waits for every row kernel still in flight
-            text, offs = jobs[0][0], jobs[0][1]
-            rag = tok.encode_packed(text, offs, max_len=None)
-            assert np.array_equal(np.minimum(np.diff(rag["row_off"]), jobs[0][3]), jobs[0][4]["n_real"])
-    hist = ctx.timing_history(64)
-    assert len(hist) == 2 * len(jobs) and all(t > 0 for t in hist)
-    for _, offs, n, L, want, d_t, d_o, d_i, d_m, d_r in jobs:
-        ids = np.empty((n, L), np.int32); mask = np.empty((n, L), np.int32); nr = np.empty(n, np.int32)
-        ctx.d2h(ids, d_i); ctx.d2h(mask, d_m); ctx.d2h(nr, d_r)
-        assert np.array_equal(ids, want["input_ids"]) and np.array_equal(mask, want["attention_mask"])
-        assert np.array_equal(nr, want["n_real"])
-    # the exchange step's compaction takes its place behind the LAST call's row kernel
-    _, offs, n, L, want, d_t, d_o, d_i, d_m, d_r = jobs[-3]
-    ctx.encode_device(d_t, d_o, 0, 0, n, L, flags, n * L, d_i, d_m, d_n_real=d_r, h_text_off=offs)
-    d_blk = ctx.alloc(4 * (n + n * L))
-    total = ctx.compact_block(d_i, d_r, n, L, d_blk, bits=16)
-    assert total == int(want["n_real"].sum())
-    ctx.sync()
-    for job in jobs:
-        for p in job[5:]:
-            ctx.free(p)
-    ctx.free(d_blk)
-
-
 def test_chained_device_calls(tok, sampler):
     """Dense calls with host offsets are enqueued behind one another without a host sync (same workspace, stream order):
     five different batches of growing and shrinking size, chained, must each equal their stand-alone result."""
