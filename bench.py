@@ -286,6 +286,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-verify", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the N=1 secondary measurements")
+    ap.add_argument("--switches", default="", help='(diagnostic) library switches for this run, "key=value,...": gz_debug_set through gz_switches.py')
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -344,6 +345,8 @@ def main():
     import corpus
     from genz_tokenize import Tokenize, _native
     from genz_tokenize.distributed import rank_shards, global_shard_id, GatherRound, csr_words
+    import gz_switches
+    switched = gz_switches.apply(args.switches) if args.switches else gz_switches.apply()      # (before any context exists)
     tok = Tokenize(device=device)
     tok._sync_tables()
     ctx = tok._ctx
@@ -351,14 +354,16 @@ def main():
     xbits = 16 if tok.vocab_size() <= 65536 and max(tok._special_ids()) < 65536 else 32   # ids are < len(encoder)
 
     gather = (world > 1 or args.force_exchange) and not args.no_gather
+    LOOK = 2                                                     # encode calls enqueued ahead of the exchange step that is being issued
     shards = []
     for s, text, offs, _ in made:
         sh = {"id": s, "text": text, "offs": offs, "n": len(offs) - 1, "in_bytes": int(offs[-1])}
         sh["d_text"] = ctx.alloc(sh["in_bytes"] + 64); ctx.h2d(sh["d_text"], text)
         sh["d_off"] = ctx.alloc(8 * (sh["n"] + 1)); ctx.h2d(sh["d_off"], offs)
-        # every shard keeps its own outputs in HBM (the job's result: 20.5 GB of ids + mask at N=1).  With one shard per
-        # rank a second set is needed: step k is tokenized into set k & 1 while the exchange of step k-1 is in flight.
-        nset = 2 if (gather and len(made) == 1) else 1
+        # every shard keeps its own outputs in HBM (the job's result: 20.5 GB of ids + mask at N=1).  With an exchange, the block of
+        # call c leaves while calls c + 1 .. c + LOOK are already enqueued: a shard that comes round again within LOOK + 1 calls needs
+        # that many output sets (one shard per rank: 3 sets; two: 2)
+        nset = -(-(LOOK + 1) // len(made)) if gather else 1
         sh["sets"] = [{"ids": ctx.alloc(4 * sh["n"] * L), "mask": ctx.alloc(4 * sh["n"] * L), "nreal": ctx.alloc(4 * sh["n"])}
                       for _ in range(nset)]
         if gather:
@@ -407,17 +412,28 @@ def main():
                 ctx.h2d(d_dst + 4 * w0, buf)
             w0 += k
 
+    # what one exchange step costs the HOST, per step (seconds; the timed region appends): the blocking wait for THIS shard's
+    # compact kernel, the size exchange over gloo, the enqueue of the gather -- and, on the device, the gather itself (events on the
+    # exchange stream: gz_exchange_timing_history, read after the timed region)
+    xt = {"compact_sync": [], "size_exchange": [], "gather_host": [], "block_bytes": []}
+    x_on = [False]
+    size_in = torch.zeros(1, dtype=torch.int64) if dist is not None else None
+    size_out = torch.zeros(world, dtype=torch.int64) if dist is not None else None
+
     def exchange(j, st):
         """Exchange step of local shard j: every rank sends the shard's rows WITHOUT the padding -- ONE block [row lengths | the
         rows' real entries] -- straight to rank 0 over its own xGMI link (one grouped ncclSend / ncclRecv per shard).  The host
         waits for the compact kernel of THIS shard only (the next shard's kernels are already queued on the main stream), then
-        the ranks tell each other their block sizes over gloo."""
+        the ranks tell each other their block sizes over gloo (ONE all-gather into a preallocated int64 tensor: no pickling)."""
         r = rounds[j]
         plan = r["plan"]
+        t_a = time.perf_counter()
         total = ctx.compact_block(st["ids"], st["nreal"], n, L, st["block"], bits=xbits)
-        lst = [None] * world
-        dist.all_gather_object(lst, int(total))
-        plan.announce(lst)                                        # entries per rank -> words per rank (n_real header not included)
+        t_b = time.perf_counter()
+        size_in[0] = int(total)
+        dist.all_gather_into_tensor(size_out, size_in)
+        t_c = time.perf_counter()
+        plan.announce(size_out.tolist())                          # entries per rank -> words per rank (n_real header not included)
         words = [n + w for w in plan.words]                      # a block = n row lengths + the entries
         if rank == 0 and sum(words) > plan.capacity:
             sys.exit("bench: receive buffer too small (cannot happen: it holds the worst case)")
@@ -425,27 +441,35 @@ def main():
             gloo_gatherv(st["block"], words[rank], r["recv"], words)
         else:
             ctx.gather_rows(st["block"], words[rank], 1, r["recv"] if rank == 0 else 0, words, 0)
+        t_d = time.perf_counter()
         r["words"] = words
+        if x_on[0]:
+            xt["compact_sync"].append(t_b - t_a); xt["size_exchange"].append(t_c - t_b); xt["gather_host"].append(t_d - t_c)
+            xt["block_bytes"].append(4 * words[rank])
 
     kernel_ms = []
     step_no = [0]
 
     def run_steps(k_steps, record):
-        """k_steps passes over the job; with an exchange, a shard's kernels overlap the exchange of the one before."""
-        prev = None
+        """k_steps passes over the job; with an exchange, the block of call c leaves when calls c + 1 .. c + LOOK have been enqueued:
+        the GPU always has a launch queued while the host does the exchange's control part (a blocking wait for the compact
+        kernel's total, the size exchange over gloo, the gather's enqueue)."""
+        import collections
+        waiting = collections.deque()
         for _ in range(k_steps):
             for j, sh in enumerate(shards):
                 st = sh["sets"][step_no[0] % len(sh["sets"])]
                 ctx.encode_device(sh["d_text"], sh["d_off"], 0, 0, sh["n"], L, flags, sh["n"] * L, st["ids"], st["mask"],
                                   d_n_real=st["nreal"], h_text_off=sh["offs"])
-                if gather and prev is not None:
-                    ctx.exchange_select(1)
-                    exchange(*prev)
-                prev = (j, st)
+                if gather:
+                    waiting.append((j, st))
+                    if len(waiting) > LOOK:
+                        ctx.exchange_select(LOOK)
+                        exchange(*waiting.popleft())
             step_no[0] += 1
-        if gather and prev is not None:
-            ctx.exchange_select(0)
-            exchange(*prev)
+        while waiting:
+            ctx.exchange_select(len(waiting) - 1)
+            exchange(*waiting.popleft())
         # the launches were enqueued back to back (no host sync between them unless the exchange needs one); this
         # synchronises and reads the hipEvent pairs recorded around every call's launches on the library's stream
         hist = ctx.timing_history(1024)
@@ -459,10 +483,23 @@ def main():
 
     run_steps(args.warmup, False)
     fence()
+    if gather and not gloo:
+        ctx.exchange_timing_history()                                # (forget the warm-up's gathers)
+    x_on[0] = True
     t0 = time.perf_counter()
     run_steps(args.steps, True)
     fence()
     elapsed = time.perf_counter() - t0
+    x_on[0] = False
+    xinfo = None
+    if gather:
+        # the exchange step, taken apart (per step = per shard; mean over this rank's steps, then the MAX over the ranks)
+        dev_ms = ctx.exchange_timing_history() if not gloo else []
+        mine = [float(np.mean(xt[k])) * 1e3 if xt[k] else 0.0 for k in ("compact_sync", "size_exchange", "gather_host")]
+        mine += [float(np.mean(dev_ms)) if dev_ms else 0.0, float(np.max(dev_ms)) if dev_ms else 0.0, float(np.mean(xt["block_bytes"])) if xt["block_bytes"] else 0.0]
+        tx = torch.tensor(mine, dtype=torch.float64)
+        dist.all_reduce(tx, op=dist.ReduceOp.MAX)
+        xinfo = [float(v) for v in tx.tolist()]
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -565,7 +602,7 @@ def main():
         in_b = shards[0]["in_bytes"] if m == 1 else float(np.mean([sh["in_bytes"] for sh in shards]))
         algo = _algo_bytes(in_b, n, L)
         achieved = algo / (k_ms * 1e-3) / 1e9
-        shard_traffic = _pmc_traffic("r04_pmc_traffic_shard.json")
+        shard_traffic = _pmc_traffic("r05_pmc_traffic_shard.json")
         out = {
             "metric": "UTF-8 MB/s tokenized (Tokenize.__call__ hot path: split + BPE + vocab lookup + pad/trunc + mask)",
             "value": round(total_bytes * args.steps / elapsed / 1e6, 2),
@@ -600,15 +637,36 @@ def main():
                          # the text is streamed twice with 16-byte-per-lane loads (classify, words), which FETCH_SIZE counts at half
                          # their bytes on gfx950 (MI355X_MICROARCH.md, HBM): the corrected figure adds the uncounted half of both passes
                          "traffic_corrected": int(shard_traffic["bytes_per_step"] + in_b) if shard_traffic else None,
-                         "traffic_note": ("profiles/r04_pmc_traffic_shard.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over one "
+                         "traffic_note": ("profiles/r05_pmc_traffic_shard.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over one "
                                           "launch on shard 0 (1.25 M documents), same kernel sources (sha %s); reads of 16-B streams are "
                                           "half-counted on gfx950, not corrected" % kernel_source_sha16()) if shard_traffic else
-                                         "null: profiles/r04_pmc_traffic_shard.json is absent or was taken on other kernel sources",
+                                         "null: profiles/r05_pmc_traffic_shard.json is absent or was taken on other kernel sources",
                          "algorithmic_bytes_per_launch": int(algo),
                          "kernel_ms_avg": round(k_ms, 4), "launches_timed": len(kernel_ms),
                          "timed_with": "hipEvents on the library's stream around each launch of the pipeline, inside the timed region"},
             "verified": verify, "verified_items": checked if len(checked) <= 24 else checked[:24] + ["..."],
         }
+        if switched:
+            out["switches"] = dict(switched)                         # (diagnostic run: gz_debug_set pairs in force)
+        if xinfo is not None:
+            host_ms = xinfo[0] + xinfo[1] + xinfo[2]
+            out["exchange"] = {
+                "what": "one exchange step = one shard's block [int32 row lengths | %d-bit real entries] from every peer to rank 0; per step, "
+                        "mean over a rank's steps inside the timed region, MAX over the ranks" % xbits,
+                "transport": "gloo rehearsal (D2H -> send/recv -> H2D)" if gloo else "RCCL grouped ncclSend/ncclRecv",
+                "bytes_per_peer": int(xinfo[5]),
+                "compact_sync_ms": round(xinfo[0], 4),          # host blocked until THIS shard's compact kernel has its total
+                "size_exchange_ms": round(xinfo[1], 4),         # one gloo all_gather_into_tensor of an int64
+                "gather_enqueue_ms": round(xinfo[2], 4),        # host time of gz_gather_rows (gloo rehearsal: the whole transfer)
+                "gather_enqueue_to_done_ms": None if gloo else round(xinfo[3], 4),     # hipEvents on the exchange stream
+                "gather_enqueue_to_done_ms_max": None if gloo else round(xinfo[4], 4),
+                "link_GB_per_s_per_peer": None if (gloo or xinfo[3] <= 0) else round(xinfo[5] / (xinfo[3] * 1e-3) / 1e9, 2),
+                "host_control_ms": round(host_ms, 4),
+                "kernels_ms_per_step": round(k_ms, 4),
+                # the exchange of shard k runs under the kernels of shard k + 1: it is hidden while both the host's part and the
+                # transfer stay under one launch's kernels
+                "hidden_under_kernels": bool(host_ms < k_ms and (gloo or xinfo[3] < k_ms)),
+            }
         out.update(sec)
         if "headline_host_paths" in sec:
             # timing (ii) of SURVEY.md 8(d) for the SAME job, first-class: pinned host text in, pinned CSR rows out (PCIe-bound)
@@ -681,7 +739,7 @@ def secondary(ctx, tok, flags, args, cfg2):
     n_tok = int(mask.sum(dtype=np.int64))
     del ids, mask
     algo = _algo_bytes(R.in_bytes, R.n, L)
-    traffic = _pmc_traffic("r04_pmc_traffic.json")
+    traffic = _pmc_traffic("r05_pmc_traffic.json")
     # (ii) device end-to-end: host buffers in, host buffers out (PCIe both ways).  The library's host path for batches is
     # gz_encode_batch_csr: sub-batches, text H2D / kernels / D2H on three streams, and only the rows' real entries
     # (16-bit) + 4 bytes per document come back; the buffers are pinned (gz_host_alloc), as SURVEY.md 8(d) (ii) says.
@@ -710,26 +768,38 @@ def secondary(ctx, tok, flags, args, cfg2):
     r = tok.encode_batch(docs, max_len=L)
     py_e2e = time.perf_counter() - t_a
     ok_py = int(r["attention_mask"].sum(dtype=np.int64)) == n_tok
-    del r, docs, raw
+    del r
+    # (iii') the path a model-feed user takes: list of str in, dense [N, L] rows LEFT IN HBM (DLPack hand-off): packing + H2D of the text +
+    # kernels; only n_real [N] comes back
+    py_dev = []
+    for _ in range(2):
+        t_a = time.perf_counter()
+        dv = tok.encode_to_device(docs, max_len=L)
+        py_dev.append(time.perf_counter() - t_a)
+        ok_py = ok_py and int(np.asarray(dv["n_real"]).sum(dtype=np.int64)) == n_tok
+        del dv
+    del docs, raw
     out["configs_2_roofline_run"] = {
         "workload": "BASELINE configs[2]: %d mixed-length sentences (%.1f MB), max_len=%d, one launch of the pipeline" % (R.n, R.in_bytes / 1e6, L),
         "verified": "reference sha256 (tests/golden/g5_hashes.json cfg3_1M, computed by the reference itself): match",
         "timings": {"kernels_ms": round(k_ms, 4), "device_e2e_ms": round(min(e2e) * 1e3, 3), "python_e2e_ms": round(py_e2e * 1e3, 2),
+                    "python_to_device_ms": round(min(py_dev) * 1e3, 2),
                     "device_e2e_dense_pageable_ms": round(min(e2e_dense) * 1e3, 2), "device_e2e_bytes_over_pcie": int(R.in_bytes + 8 * (R.n + 1) + csr_bytes),
                     "MB_per_s": {"kernels": round(R.in_bytes / k_ms / 1e3, 1), "device_e2e": round(R.in_bytes / min(e2e) / 1e6, 1), "device_e2e_dense_pageable": round(R.in_bytes / min(e2e_dense) / 1e6, 1),
-                                 "python_e2e": round(R.in_bytes / py_e2e / 1e6, 1)},
+                                 "python_e2e": round(R.in_bytes / py_e2e / 1e6, 1), "python_to_device": round(R.in_bytes / min(py_dev) / 1e6, 1)},
                     "what": "(i) hipEvents around the launches, inputs/outputs in HBM; (ii) gz_encode_batch_csr on pinned host buffers: "
                             "text + offsets H2D, kernels, D2H of n_real + the rows' real entries (16-bit), sub-batches on three streams "
                             "(device_e2e_dense_pageable_ms: gz_encode_batch returning dense [N, L] ids + mask into pageable numpy arrays); "
-                            "(iii) Tokenize.encode_batch(list of str): UTF-8 packing + the dense host path.  Token totals of (ii)/(iii) "
+                            "(iii) Tokenize.encode_batch(list of str): UTF-8 packing + the dense host path; python_to_device_ms: "
+                            "Tokenize.encode_to_device(list of str) -- packing, text H2D, kernels, the dense rows stay in HBM (DLPack).  Token totals of (ii)/(iii) "
                             "equal (i): %s" % (ok_e2e and ok_py)},
         "roofline": {"bound": "hbm", "achieved": round(algo / k_ms / 1e6, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(algo / k_ms / 1e6 / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_launch": int(algo),
                      "kernel_ms_avg": round(k_ms, 4),
                      "traffic": traffic["bytes_per_step"] if traffic else None,
-                     "traffic_source": "profiles/r04_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, summed over the "
+                     "traffic_source": "profiles/r05_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, summed over the "
                                        "launch's kernels; reads not corrected for the gfx950 half-count)" if traffic else
-                                       "none for this build (profiles/r04_pmc_traffic.json absent or taken on other kernel sources)"}}
+                                       "none for this build (profiles/r05_pmc_traffic.json absent or taken on other kernel sources)"}}
     # ---- the same step with the whole-word tables off: every word through the merge loop
     k2 = R.kernel_ms(flags | _native.GZ_NO_WORD_TABLE, reps=3)
     out["merge_loop_only"] = {"kernel_ms_avg": round(k2, 4), "MB_per_s_kernel": round(R.in_bytes / k2 / 1e3, 1)}
@@ -827,16 +897,39 @@ def secondary(ctx, tok, flags, args, cfg2):
             sys.exit("bench: " + e5)
         v5 = "C-oracle sha256 over all %d documents (tests/golden/g5_hashes.json cfg5_50k; its first 300 documents also hashed by the reference): match" % R5.n
     a5 = _algo_bytes(R5.in_bytes, R5.n, L5)
-    t5j = _pmc_traffic("r04_pmc_traffic_cfg4.json")
+    t5j = _pmc_traffic("r05_pmc_traffic_cfg4.json")
+    # ... and the unpadded run SURVEY.md 8(d) asks for beside it (max_len=None: ragged rows + row offsets; parity: the suite's
+    # test_cfg5_full_size_padded_and_unpadded): kernels by hipEvents, inputs / outputs resident
+    c5 = tok5._ctx
+    cap5 = R5.in_bytes + 2 * R5.n
+    d_ri, d_rm, d_ro = c5.alloc(4 * cap5), c5.alloc(4 * cap5), c5.alloc(8 * (R5.n + 1))
+    rag_flags = _native.GZ_PADDING | _native.GZ_TRUNCATION | _native.GZ_MAX_LEN_NONE | _native.GZ_TIMING
+    rag = []
+    for _ in range(4):
+        c5.encode_device(R5.d_text, R5.d_off, 0, 0, R5.n, 0, rag_flags, cap5, d_ri, d_rm, d_row_off=d_ro, d_n_real=R5.d_nreal, h_text_off=R5.offs)
+        c5.sync()
+        rag.append(c5.timing()[3])
+    ro5 = np.empty(R5.n + 1, dtype=np.int64); c5.d2h(ro5, d_ro)
+    u5 = None
+    if d5 and d5["n_docs"] == R5.n and "unpadded" in d5:
+        u5 = int(ro5[-1]) == int(d5["unpadded"]["n_tokens"])        # (the rows themselves: tests/test_gpu_parity.py, whole digests)
+    a5u = R5.in_bytes + 8 * (R5.n + 1) + 8 * int(ro5[-1]) + 8 * (R5.n + 1) + 4 * R5.n        # text + offsets in; ids + mask + row offsets + n_real out
+    for q in (d_ri, d_rm, d_ro):
+        c5.free(q)
     out["configs_4_long_docs"] = {
         "workload": "BASELINE configs[4]: Tokenize.fromFile custom tables (100 000-entry vocab, %d merges without the #version header), "
                     "%d documents of <= 4 000 characters (%.1f MB), max_len=%d pad+trunc" % (tok5._ctx.table_info()[2], R5.n, R5.in_bytes / 1e6, L5),
         "kernel_ms_avg": round(k5, 4), "MB_per_s_kernel": round(R5.in_bytes / k5 / 1e3, 1), "verified": v5,
+        "unpadded_run": {"what": "the same documents with max_len=None (ragged rows + int64 row offsets): all kernels of the call by hipEvents",
+                         "kernel_ms_avg": round(float(np.mean(rag[1:])), 4), "MB_per_s_kernel": round(R5.in_bytes / float(np.mean(rag[1:])) / 1e3, 1),
+                         "tokens": int(ro5[-1]), "algorithmic_bytes": int(a5u),
+                         "roofline_frac": round(a5u / float(np.mean(rag[1:])) / 1e6 / HBM_PEAK_GBS, 5),
+                         "token_total_matches_digest_file": u5},
         "roofline": {"bound": "hbm", "achieved": round(a5 / k5 / 1e6, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(a5 / k5 / 1e6 / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_launch": int(a5),
                      "traffic": t5j["bytes_per_step"] if t5j else None,
-                     "traffic_source": "profiles/r04_pmc_traffic_cfg4.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/prof_cfg5.py)"
-                                       if t5j else "none for this build (profiles/r04_pmc_traffic_cfg4.json absent or taken on other kernel sources)"}}
+                     "traffic_source": "profiles/r05_pmc_traffic_cfg4.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/prof_cfg5.py)"
+                                       if t5j else "none for this build (profiles/r05_pmc_traffic_cfg4.json absent or taken on other kernel sources)"}}
     R5.free()
     return out
 

@@ -127,6 +127,10 @@ struct gz_ctx {
     hipStream_t xstream = nullptr;
     hipEvent_t ev_tok[4] = {nullptr, nullptr, nullptr, nullptr};   // end of the last four encode calls
     hipEvent_t ev_x = nullptr;                                       // last exchange operation issued
+    // gz_gather_rows, timed: a pair of events on the exchange stream around every gather (gz_exchange_timing_history)
+    static constexpr int XRING = 64;
+    hipEvent_t xring[XRING][2] = {};
+    uint64_t xring_n = 0;
     uint64_t enc_seq = 0;
     int x_back = 0;                                                  // exchange ops depend on encode call (last - x_back)
     bool x_used = false;
@@ -837,6 +841,7 @@ void gz_destroy(gz_ctx* c)
         for (DBuf* b : {&t.brk, &t.st, &t.en, &t.blkcnt, &t.docw0, &t.wtok, &t.waux, &t.mtok, &t.mlist, &t.blkmiss, &t.tilecnt, &t.wlist, &t.grpblk, &t.lookback, &t.mq}) release(*b);
     for (auto& ev : c->ev) if (ev) hipEventDestroy(ev);
     for (auto& pr : c->ring) { if (pr[0]) hipEventDestroy(pr[0]); if (pr[1]) hipEventDestroy(pr[1]); }
+    for (auto& pr : c->xring) { if (pr[0]) hipEventDestroy(pr[0]); if (pr[1]) hipEventDestroy(pr[1]); }
     if (c->h_flags) hipHostFree(c->h_flags);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -1972,6 +1977,9 @@ int gz_gather_rows(gz_ctx* c, const int32_t* send_dev, int64_t n_rows_local, int
     HIPCHK(c, hipSetDevice(c->device));
     const int ncclInt32 = 2;
     { int rc0 = x_begin(c); if (rc0) return rc0; }
+    hipEvent_t* xe = c->xring[c->xring_n % gz_ctx::XRING];
+    if (!xe[0]) { HIPCHK(c, hipEventCreate(&xe[0])); HIPCHK(c, hipEventCreate(&xe[1])); }
+    HIPCHK(c, hipEventRecord(xe[0], c->xstream));                // (behind whatever the exchange stream waits for: the gather's own start)
     // the root's own block is a device-to-device copy (outside the group: it is not an RCCL operation)
     if (c->rank == root && n_rows_local > 0) {
         int64_t row0 = 0;
@@ -2001,7 +2009,28 @@ int gz_gather_rows(gz_ctx* c, const int32_t* send_dev, int64_t n_rows_local, int
     }
     if (r != 0)
         return fail(c, GZ_E_RCCL, "RCCL gather failed: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error");
+    HIPCHK(c, hipEventRecord(xe[1], c->xstream));
+    c->xring_n++;
     { int rc1 = x_end(c); if (rc1) return rc1; }
+    return GZ_OK;
+}
+
+int gz_exchange_timing_history(gz_ctx* c, double* out_ms, int32_t max, int32_t* n_out)
+{
+    if (!c || !out_ms || !n_out || max < 0) return GZ_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->xstream) HIPCHK(c, hipStreamSynchronize(c->xstream));
+    int n = (int)(c->xring_n < (uint64_t)gz_ctx::XRING ? c->xring_n : (uint64_t)gz_ctx::XRING);
+    if (n > max) n = max;
+    for (int i = 0; i < n; ++i) {
+        const uint64_t k = c->xring_n - (uint64_t)n + (uint64_t)i;
+        float ms = 0;
+        HIPCHK(c, hipEventElapsedTime(&ms, c->xring[k % gz_ctx::XRING][0], c->xring[k % gz_ctx::XRING][1]));
+        out_ms[i] = ms;
+    }
+    *n_out = n;
+    c->xring_n = 0;
     return GZ_OK;
 }
 

@@ -27,7 +27,7 @@ SYMBOLS = [
     "gz_vocab_entry", "gz_merge_entry", "gz_encode_batch", "gz_encode_batch_csr", "gz_host_alloc", "gz_host_free", "gz_encode_batch_device", "gz_encode_batch_device_h", "gz_sync",
     "gz_word_token_counts", "gz_bpe_word", "gz_symbol_utf8", "gz_device_alloc", "gz_device_free", "gz_memcpy_h2d", "gz_memcpy_d2h",
     "gz_timing", "gz_timing_history", "gz_decoder_snapshot", "gz_decode_batch", "gz_decode_batch_device", "gz_preprocess_batch",
-    "gz_preprocess_batch_device", "gz_block_create", "gz_block_release", "gz_block_dlpack", "gz_dlpack_capsule_destructor", "gz_exchange_select", "gz_comm_unique_id", "gz_comm_init", "gz_gather_rows", "gz_compact_rows", "gz_expand_rows", "gz_compact_rows16", "gz_expand_rows16", "gz_compact_block", "gz_expand_block",
+    "gz_preprocess_batch_device", "gz_block_create", "gz_block_release", "gz_block_dlpack", "gz_dlpack_capsule_destructor", "gz_exchange_select", "gz_comm_unique_id", "gz_comm_init", "gz_gather_rows", "gz_exchange_timing_history", "gz_compact_rows", "gz_expand_rows", "gz_compact_rows16", "gz_expand_rows16", "gz_compact_block", "gz_expand_block",
     "gz_host_tables_create", "gz_host_tables_destroy", "gz_host_tables_array", "gz_host_tables_vocab_entry",
     "gz_host_tables_merge_entry", "gz_host_tables_symbol", "gz_limit", "gz_debug_set",
 ]
@@ -93,6 +93,8 @@ def load_library():
     L.gz_comm_unique_id.argtypes = [vp]
     L.gz_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
     L.gz_gather_rows.argtypes = [vp, vp, i64, i32, vp, vp, C.c_int]
+    if hasattr(L, "gz_exchange_timing_history"):
+        L.gz_exchange_timing_history.argtypes = [vp, P(C.c_double), i32, P(i32)]
     L.gz_compact_rows.argtypes = [vp, vp, vp, i64, i32, vp, P(i64)]
     L.gz_expand_rows.argtypes = [vp, vp, vp, i64, i32, vp, vp]
     L.gz_compact_rows16.argtypes = [vp, vp, vp, i64, i32, vp, P(i64)]
@@ -365,6 +367,13 @@ class Context:
         buf = (C.c_double * max_calls)()
         n = C.c_int32()
         self._check(self.lib.gz_timing_history(self.handle, buf, max_calls, C.byref(n)))
+        return [buf[i] for i in range(n.value)]
+
+    def exchange_timing_history(self, max_calls: int = 64):
+        """Synchronise the exchange stream; start-possible -> done time (ms) of the last gz_gather_rows calls, oldest first."""
+        buf = (C.c_double * max_calls)()
+        n = C.c_int32()
+        self._check(self.lib.gz_exchange_timing_history(self.handle, buf, max_calls, C.byref(n)))
         return [buf[i] for i in range(n.value)]
 
     def timing(self):

@@ -308,6 +308,11 @@ int  gz_exchange_select(gz_ctx *ctx, int back);
 int  gz_comm_init(gz_ctx *ctx, const uint8_t id[128], int rank, int world);
 int  gz_gather_rows(gz_ctx *ctx, const int32_t *send_dev, int64_t n_rows_local, int32_t row_len,
                     int32_t *recv_dev, const int64_t *rows_per_rank, int root);
+/* Every gz_gather_rows is bracketed by a pair of events on the exchange stream: this call synchronises that stream and
+ * returns, oldest first, the time from the moment the gather COULD start (the encode call it belongs to was done, earlier
+ * exchange operations had drained) to its last byte received / sent, of the last (up to 64, up to `max`) gathers, then
+ * forgets them. */
+int  gz_exchange_timing_history(gz_ctx *ctx, double *out_ms, int32_t max, int32_t *n_out);
 
 /* Compact form of dense rows for the exchange step: most of a [n_rows, row_len] block is padding, so a rank sends
  * only the n_real[i] leading entries of every row (+ the counts) and the root re-creates padding and mask.

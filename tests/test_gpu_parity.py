@@ -853,6 +853,11 @@ assert d2._ctx.table_cache_status() == 4 and d2._ctx.table_digest() == a._ctx.ta
 os.environ["GZ_TABLE_CACHE"] = os.path.join(os.path.dirname(cdir), "deep", "er", "cache")      # parents are created (0700)
 d3, _ = load()
 assert d3._ctx.table_cache_status() == 2 and (os.stat(os.environ["GZ_TABLE_CACHE"]).st_mode & 0o777) == 0o700
+# a symbolic link to a good cache directory is not followed (the directory must be a real one of this user)
+link = os.path.join(os.path.dirname(cdir), "link"); os.symlink(cdir, link)
+os.environ["GZ_TABLE_CACHE"] = link
+d4, _ = load()
+assert d4._ctx.table_cache_status() == 4 and d4._ctx.table_digest() == a._ctx.table_digest()
 print("ok build %%.3f s, cached %%.3f s" %% (ta, tb))
 """ % root
     env = dict(os.environ, GZ_TABLE_CACHE=str(tmp_path / "cache"))
