@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (GPU box, repo root): tools/r04_final.sh <tag>   -- everything profiles/r04_* holds for one build:
+# usage (GPU box, repo root): tools/final_set.sh <tag> [round, default r05]   -- everything profiles/<round>_* holds for one build:
 #   (1) kernel stats of a bench.py run (rocprofv3 --kernel-trace --stats); (2) steady-state per-kernel times + the timeline of one
 #   launch on BASELINE configs[2]; (3) HBM traffic (separate --pmc passes, no trace domains) of configs[2], of one shard of the
 #   headline job, of BASELINE configs[4] and of configs[2] with the whole-word tables off; (4) SQ / TCP / TCC counters of the
@@ -7,6 +7,7 @@
 #   (7) the default bench line.
 set -o pipefail
 tag=$1
+ROUND=${2:-r05}
 R=$PWD
 O=$R/gpurun_out/final_$tag
 mkdir -p $O
@@ -69,7 +70,7 @@ echo "(5)" >> $O/progress.txt
 ( cd $R && python3 tools/t_load.py > $O/table_load.txt 2>&1; python3 tools/small_bench.py > $O/small_calls.txt 2>&1; tools/pp_trace.sh > $O/prepass_kernels.txt 2>&1 )
 echo "(6)" >> $O/progress.txt
 # (7) (the traffic files go where bench.py looks for them: this run's line then carries them)
-cp $O/pmc_traffic.json $R/profiles/r04_pmc_traffic.json; cp $O/pmc_traffic_shard.json $R/profiles/r04_pmc_traffic_shard.json; cp $O/pmc_traffic_cfg4.json $R/profiles/r04_pmc_traffic_cfg4.json
+cp $O/pmc_traffic.json $R/profiles/${ROUND}_pmc_traffic.json; cp $O/pmc_traffic_shard.json $R/profiles/${ROUND}_pmc_traffic_shard.json; cp $O/pmc_traffic_cfg4.json $R/profiles/${ROUND}_pmc_traffic_cfg4.json
 ( cd $R && timeout -k 10 900 python3 bench.py > $O/bench.json.log 2> $O/bench.err ) || { tail -5 $O/bench.err; exit 1; }
 tail -c 400 $O/bench.json.log
 find $O -name "*counter_collection.csv" -delete
