@@ -1007,6 +1007,9 @@ def test_bench_multirank_exchange_on_one_gpu_over_gloo(world):
     out = json.loads(line)
     assert out["n_gpus"] == world and out["config"]["shards_per_rank"] == 8 // world
     assert "gloo" in out["config"]["sharding"]
+    x = out["exchange"]                                          # the exchange step, taken apart (max over ranks)
+    assert x["bytes_per_peer"] > 0 and x["compact_sync_ms"] > 0 and x["size_exchange_ms"] > 0 and x["gather_enqueue_ms"] > 0
+    assert x["gather_enqueue_to_done_ms"] is None and isinstance(x["hidden_under_kernels"], bool)      # (device timing: RCCL transport only)
     assert len([c for c in out["verified_items"] if c.startswith("gathered shard")]) == 8     # every shard arrived and was checked
     assert out["value"] > 0
 
@@ -1030,6 +1033,9 @@ def test_bench_exchange_step_over_rccl_with_one_rank():
     assert r.returncode == 0, r.report
     out = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert out["n_gpus"] == 1 and "RCCL gatherv" in out["config"]["sharding"]
+    x = out["exchange"]                                          # ... with the gathers timed on the exchange stream (gz_exchange_timing_history)
+    assert x["bytes_per_peer"] > 0 and x["gather_enqueue_to_done_ms"] > 0 and x["gather_enqueue_to_done_ms_max"] >= x["gather_enqueue_to_done_ms"]
+    assert x["compact_sync_ms"] > 0 and x["size_exchange_ms"] > 0 and isinstance(x["hidden_under_kernels"], bool)
     assert len([c for c in out["verified_items"] if c.startswith("gathered shard")]) == 8
     assert out["value"] > 0
 
