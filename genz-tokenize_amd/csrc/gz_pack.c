@@ -9,6 +9,9 @@
  * kernels see are the same either way.  Nothing is cached inside the str objects (no PyUnicode_AsUTF8AndSize).
  *
  *   _gz_pack.pack(seq) -> (bytes text, bytes offsets)      offsets: native int64[N + 1]
+ *   _gz_pack.pack_into(seq, out, offsets) -> total bytes    the same into the caller's writable buffers (e.g. a pinned arena: no
+ *       fresh allocation of the batch's size, no second copy); offsets must hold N + 1 int64; returns -(bytes needed) and writes
+ *       nothing but the offsets when `out` is too small
  *   raises TypeError("expected string or bytes-like object") for a non-str item, like re.findall in the reference
  *   (tokenize.py:106) and _require_str in tokenize.py
  */
@@ -74,10 +77,13 @@ static void* pack_worker(void* arg)
     return NULL;
 }
 
+#include <unistd.h>
 static int n_threads(Py_ssize_t n_items)
 {
+    /* GZ_PACK_THREADS, else half the online processors, between 4 and 32 (the passes are memory-bound: beyond that nothing is gained) */
     const char* e = getenv("GZ_PACK_THREADS");
-    long t = e ? atol(e) : 8;
+    long t = e ? atol(e) : sysconf(_SC_NPROCESSORS_ONLN) / 2;
+    if (!e) { if (t < 4) t = 4; if (t > 32) t = 32; }
     if (t < 1) t = 1;
     if (t > 64) t = 64;
     if (n_items < 20000) t = 1;                                       /* small batches: thread start-up costs more than it saves */
@@ -92,6 +98,58 @@ static void run_jobs(PackJob* jobs, int nt)
     for (int k = 1; k < nt; ++k) started[k] = pthread_create(&th[k], NULL, pack_worker, &jobs[k]) == 0;
     pack_worker(&jobs[0]);
     for (int k = 1; k < nt; ++k) { if (started[k]) pthread_join(th[k], NULL); else pack_worker(&jobs[k]); }
+}
+
+/* pack_into(seq, out, offsets): see the header of this file */
+static PyObject* gz_pack_into(PyObject* self, PyObject* args)
+{
+    (void)self;
+    PyObject* arg;
+    Py_buffer outb, offb;
+    if (!PyArg_ParseTuple(args, "Ow*w*", &arg, &outb, &offb)) return NULL;
+    PyObject* seq = PySequence_Fast(arg, "expected a sequence of str");
+    if (!seq) { PyBuffer_Release(&outb); PyBuffer_Release(&offb); return NULL; }
+    const Py_ssize_t n = PySequence_Fast_GET_SIZE(seq);
+    PyObject** items = PySequence_Fast_ITEMS(seq);
+    PyObject* result = NULL;
+    Item* it = (Item*)malloc((size_t)(n > 0 ? n : 1) * sizeof(Item));
+    PyObject** held = (PyObject**)malloc((size_t)(n > 0 ? n : 1) * sizeof(PyObject*));
+    Py_ssize_t got = 0;
+    if (!it || !held) PyErr_NoMemory();
+    else if (offb.len < (n + 1) * (Py_ssize_t)sizeof(int64_t) || ((uintptr_t)offb.buf & 7)) PyErr_SetString(PyExc_ValueError, "pack_into: offsets must hold N + 1 aligned int64");
+    else {
+        int64_t* off = (int64_t*)offb.buf;
+        for (; got < n; ++got) {
+            PyObject* s = items[got];
+            if (!PyUnicode_Check(s)) { PyErr_SetString(PyExc_TypeError, "expected string or bytes-like object"); break; }
+            if (PyUnicode_READY(s) < 0) break;
+            Py_INCREF(s);
+            held[got] = s;
+            it[got].data = PyUnicode_DATA(s); it[got].len = PyUnicode_GET_LENGTH(s); it[got].kind = PyUnicode_KIND(s); it[got].ascii = PyUnicode_IS_ASCII(s);
+        }
+        if (got == n) {
+            const int nt = n_threads(n);
+            PackJob jobs[64];
+            for (int k = 0; k < nt; ++k) { jobs[k].it = it; jobs[k].off = off; jobs[k].out = NULL; jobs[k].lo = n * k / nt; jobs[k].hi = n * (k + 1) / nt; jobs[k].phase = 0; }
+            off[0] = 0;
+            int fits;
+            Py_BEGIN_ALLOW_THREADS
+            run_jobs(jobs, nt);
+            for (Py_ssize_t i = 0; i < n; ++i) off[i + 1] += off[i];
+            fits = off[n] <= (int64_t)outb.len;
+            if (fits) {
+                for (int k = 0; k < nt; ++k) { jobs[k].out = (unsigned char*)outb.buf; jobs[k].phase = 1; }
+                run_jobs(jobs, nt);
+            }
+            Py_END_ALLOW_THREADS
+            result = PyLong_FromLongLong(fits ? (long long)off[n] : -(long long)off[n]);
+        }
+    }
+    for (Py_ssize_t i = 0; i < got; ++i) Py_DECREF(held[i]);
+    free(it); free(held);
+    Py_DECREF(seq);
+    PyBuffer_Release(&outb); PyBuffer_Release(&offb);
+    return result;
 }
 
 static PyObject* gz_pack(PyObject* self, PyObject* arg)
@@ -203,6 +261,7 @@ static PyObject* gz_expand(PyObject* self, PyObject* args)
 
 static PyMethodDef methods[] = {
     {"pack", gz_pack, METH_O, "pack(seq of str) -> (utf-8 bytes, int64 offsets[N + 1] as bytes); 'surrogatepass' encoding; GZ_PACK_THREADS threads"},
+    {"pack_into", gz_pack_into, METH_VARARGS, "pack_into(seq of str, out, offsets) -> bytes written, or -(bytes needed) when out is too small"},
     {"expand", gz_expand, METH_VARARGS, "expand(tokens, bits, n_real, row_off, max_len, pad_id, ids_out, mask_out): CSR rows -> dense [N, max_len] int32"},
     {NULL, NULL, 0, NULL}};
 

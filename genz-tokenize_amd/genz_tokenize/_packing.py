@@ -13,6 +13,24 @@ except ImportError:                             # pragma: no cover
     _gz_pack = None
 
 
+def pack_pinned(texts: Sequence[str], holder, ctx):
+    """`pack` straight into a page-locked arena `holder` keeps (holder._pin_text: grown when too small): no fresh buffer of the
+    batch's size, no second copy, and the H2D copy that follows is real DMA.  Returns (uint8 view of the arena, int64 offsets).
+    Falls back to `pack` when the C packer is not built."""
+    if _gz_pack is None or not hasattr(_gz_pack, "pack_into") or len(texts) < 8:
+        return pack(texts)
+    off = np.empty(len(texts) + 1, dtype=np.int64)
+    arena = getattr(holder, "_pin_text", None)
+    if arena is None:
+        arena = holder._pin_text = ctx.pinned_empty(1 << 24, np.uint8)
+    n = _gz_pack.pack_into(texts, arena, off)
+    if n < 0:                                        # too small: the call said how much it takes
+        arena = holder._pin_text = None
+        arena = holder._pin_text = ctx.pinned_empty(int(-n * 1.25) + 4096, np.uint8)
+        n = _gz_pack.pack_into(texts, arena, off)
+    return arena[:n], off
+
+
 def pack(texts: Sequence[str]):
     """(uint8 buffer, int64 offsets[N + 1]); TypeError("expected string or bytes-like object") for a non-str item --
     what `re.findall` raises in the reference (tokenize.py:106)."""

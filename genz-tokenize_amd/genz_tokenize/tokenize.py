@@ -339,27 +339,25 @@ class Tokenize(object):
         dense [N, max_len] arrays the caller gets are filled from the CSR rows by host threads -- the same values as the
         dense device path, without 2 * N * max_len * 4 bytes of mostly padding crossing PCIe into pageable memory."""
         self._sync_tables()
-        tb, to = _pack(texts)
+        ctx = self._ctx
+        tb, to = _packing.pack_pinned(texts, self, ctx)               # (straight into the pinned text arena)
         n = len(to) - 1
         nbytes = int(to[-1]) if n else 0
         sp = self._special_ids()
         bits = 16 if self.vocab_size() <= 65536 and max(sp) < 65536 and min(sp) >= 0 else 32
-        ctx = self._ctx
         arena = getattr(self, "_arena", None)
         cap = max(min(n * max_len, nbytes + 2 * n), 1)
-        if arena is None or arena["text"].size < nbytes or arena["tok"].size * arena["tok"].itemsize < cap * 4 or arena["nr"].size < n:
-            arena = dict(text=ctx.pinned_empty(max(int(nbytes * 1.25), 1 << 20), np.uint8),
-                         tok=ctx.pinned_empty(max(int(cap * 1.25), 1 << 18), np.int32), nr=ctx.pinned_empty(max(int(n * 1.25), 1024), np.int32))
+        if arena is None or arena["tok"].size * arena["tok"].itemsize < cap * 4 or arena["nr"].size < n:
+            arena = dict(tok=ctx.pinned_empty(max(int(cap * 1.25), 1 << 18), np.int32), nr=ctx.pinned_empty(max(int(n * 1.25), 1024), np.int32))
             self._arena = arena
-        arena["text"][:nbytes] = tb
         flags = 0 if word_table else _native.GZ_NO_WORD_TABLE
         tokbuf = arena["tok"].view(np.uint16)[:2 * arena["tok"].size] if bits == 16 else arena["tok"]
         try:
-            tokens, n_real = ctx.encode_csr(arena["text"][:nbytes], to, max_len, bits, flags, tokens=tokbuf, n_real=arena["nr"])
+            tokens, n_real = ctx.encode_csr(tb, to, max_len, bits, flags, tokens=tokbuf, n_real=arena["nr"])
         except _native.GzError as e:
             if bits == 16 and e.code == _native.GZ_E_LIMIT:              # an id collision pushed an id past 65535
                 bits = 32
-                tokens, n_real = ctx.encode_csr(arena["text"][:nbytes], to, max_len, 32, flags, tokens=arena["tok"], n_real=arena["nr"])
+                tokens, n_real = ctx.encode_csr(tb, to, max_len, 32, flags, tokens=arena["tok"], n_real=arena["nr"])
             else:
                 raise
         row_off = np.zeros(n + 1, dtype=np.int64)
@@ -421,7 +419,7 @@ class Tokenize(object):
             raise ValueError("encode_to_device needs max_len >= 1 (dense rows)")
         self._sync_tables()
         ctx, L = self._ctx, int(max_len)
-        t, to = _pack(texts)
+        t, to = _packing.pack_pinned(texts, self, ctx)                 # (a pinned arena this object keeps: the H2D copy is real DMA)
         n = len(to) - 1
         pair = pair_texts is not None
         if pair:

@@ -94,6 +94,19 @@ def test_string_packer_matches_python_encoding():
         parts = [d.encode("utf-8", "surrogatepass") for d in seq]
         assert b == b"".join(parts)
         assert np.frombuffer(o, np.int64).tolist() == [0] + np.cumsum([len(p) for p in parts], dtype=np.int64).tolist()
+    # pack_into: the same bytes into the caller's buffers (a pinned arena in the product); too small -> -(bytes needed), nothing written
+    want = b"".join(d.encode("utf-8", "surrogatepass") for d in docs)
+    arena = np.full(len(want) + 100, 0xEE, dtype=np.uint8)
+    offs = np.empty(len(docs) + 1, dtype=np.int64)
+    assert _packing._gz_pack.pack_into(docs, arena, offs) == len(want)
+    assert arena[:len(want)].tobytes() == want and (arena[len(want):] == 0xEE).all()
+    assert offs.tolist() == [0] + np.cumsum([len(d.encode("utf-8", "surrogatepass")) for d in docs], dtype=np.int64).tolist()
+    small = np.full(len(want) - 1, 0xEE, dtype=np.uint8)
+    assert _packing._gz_pack.pack_into(docs, small, offs) == -len(want) and (small == 0xEE).all()
+    with pytest.raises(ValueError):
+        _packing._gz_pack.pack_into(docs, arena, np.empty(len(docs), dtype=np.int64))
+    with pytest.raises(TypeError, match="expected string or bytes-like object"):
+        _packing._gz_pack.pack_into(docs[:8] + [None], arena, offs)
     buf, off = _packing.pack(docs)
     assert buf.tobytes() == b"".join(d.encode("utf-8", "surrogatepass") for d in docs)
     assert off.dtype == np.int64 and len(off) == len(docs) + 1
