@@ -88,7 +88,7 @@ struct gz_ctx {
         GzPairArgs P{};
         bool timing = false;
         std::vector<GzAsmArgs> subs;   // sub-batches of the call (contiguous document ranges)
-        int use_words = 0;             // bit 0: whole-word table; bits 8..: timing diagnostics (GZ_ABLATE)
+        int use_words = 0;             // bit 0: whole-word table; bits 8..: timing diagnostics (switch `ablate`, diagnostic build)
         // small batches: ONE fused launch (gz_small_kernel) instead of the pipeline
         bool small = false, s_dense = true;
         int small_G = 0;

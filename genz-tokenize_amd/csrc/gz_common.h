@@ -92,7 +92,7 @@ inline size_t gz_tab_slack() { return (size_t)gz_default_options().tab_slack; }
 // ds_read_u16 and ONE global load from a DENSE table (load <= 0.8) that stays resident in every XCD's L2 -- no probe
 // loop, no tail, no empty-slot slack.  The key is always compared in full, so what a probe returns never depends on
 // the hash functions.  A bucket the builder could not place (never seen on real tables; forced by the tests through
-// GZ_PH_FORCE_OVERFLOW) gets d = GZ_PH_OVERFLOW: its keys are inserted by linear probing from their slot, and only
+// the switch ph_force_overflow) gets d = GZ_PH_OVERFLOW: its keys are inserted by linear probing from their slot, and only
 // lookups that land in such a bucket ever probe further.
 // ---------------------------------------------------------------------------------------------------------
 constexpr uint32_t GZ_PH_MUL = 0x2C1B3C6Du;

@@ -49,14 +49,14 @@ struct GzTextBufs {              // one text (A or B) of a batch and its per-cal
     uint4* mlist;                // [words] the misses of block b, compact, at mlist[blkcnt[b] ...]: {word index, byte offset, pending record, 0}
     uint32_t* blkmiss;           // [nblk+1] number of misses per block; scanned in place before the merge pre-pass ([nblk] = total)
     uint32_t* grpblk;            // [words/64 + 2] block that holds miss number 64 g (written by the scan)
-    uint32_t* tcnt;              // [words/2048 + 2] per 2 048-miss tile of mq: records the merge kernel takes | its chunks of 64 with a word of > 8 symbols << 16 (gz_mpre_kernel)
+    uint32_t* tcnt;              // [words/1024 + 8] per 3 072-miss tile of mq: records the merge kernel takes | its chunks of 64 with a word of > 8 symbols << 16 (gz_mpre_kernel)
     int64_t wmax;                // upper bound of the number of words (sizes of the per-word arrays)
     uint32_t* ctl;               // [64] zeroed per call: [0] words for gz_long_kernel, [1] unused, [2] [3] ticket counters of the
                                  // chained scans, [4] cursor of the compact token area; wlist == ctl + 64
     uint4* mq;                   // [words] the misses, tile by tile (1 024) sorted by symbol count: {word index, byte offset, record, 0}
     uint64_t* lookback;          // [nblk / 4 + 2] chained-scan words of gz_scan32m_kernel {status:2, call:30, value:32}; never cleared
     uint32_t epoch;              // call number written into / expected in the chained-scan words
-    uint32_t near_lim;           // places of the compact token area below this get near records (2^25; GZ_NEAR_LIMIT: smaller, for tests)
+    uint32_t near_lim;           // places of the compact token area below this get near records (2^25; switch near_limit: smaller, for tests)
     uint32_t* blklong;           // [nblk] block holds a word for gz_long_kernel (zeroed per call)
     uint32_t* wlist;             // [0] count, then the words (indices) that need 32 or 64 lanes (zeroed count per call); from the END of the
                                  // array down (wlist[wmax + 6 - k]): the words gz_long_kernel takes
