@@ -17,6 +17,8 @@ cfg = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 tok = Tokenize(); tok._sync_tables(); ctx = tok._ctx
 seed = int(os.environ["SEED"]) if os.environ.get("SEED") else None       # (SEED=100, 1250000 documents: shard 0 of BASELINE configs[3])
 text, offs, L = corpus.config_corpus(cfg, n_docs=n_docs, seed=seed)
+if os.environ.get("TYPOS"):                          # TYPOS=0.2: that fraction of the words replaced by random letters (bench.py's oov_sensitivity)
+    text = corpus.add_typos(text, offs, 7, float(os.environ["TYPOS"]))
 n = len(offs) - 1
 d_text = ctx.alloc(len(text) + 64); ctx.h2d(d_text, text)
 d_off = ctx.alloc(8 * (n + 1)); ctx.h2d(d_off, offs)
