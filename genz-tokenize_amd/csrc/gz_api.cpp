@@ -1136,21 +1136,26 @@ static int encode_host_locked(gz_ctx* c, const uint8_t* text, const int64_t* tex
             }
             if ((rc0 = ensure(c, c->w_stage, need))) return rc0;
             uint8_t* H = c->h_stage;
-            uint8_t* D = (uint8_t*)c->w_stage.p;
+            // A call this small is latency, not bandwidth: the kernels work straight on the pinned block (page-locked host memory is
+            // device-accessible; a README-sized call reads ~ 100 bytes over the bus and writes as few) -- two copies and their stream
+            // round trips less per call.  Only when the one-launch kernel will take it (it touches its text once).
+            // (not for ragged pairs: their row scan, finalize and pair kernels read the rows several times -- 60 -> 70 us over the bus)
+            const bool direct = c->opt.host_direct > 0 && c->opt.small && o_end <= (size_t)c->opt.host_direct && !(flags & GZ_KEEP_WORDS) && !(is_pair && !dense);
+            uint8_t* D = direct ? H : (uint8_t*)c->w_stage.p;
             std::memcpy(H, text_off, off_b);
             if (tbs) std::memcpy(H + in_text, text + text_off[0], (size_t)tbs);
             if (is_pair) {
                 std::memcpy(H + in_poff, pair_off, off_b);
                 if (pbs) std::memcpy(H + in_pair, pair + pair_off[0], (size_t)pbs);
             }
-            HIPCHK(c, hipMemcpyAsync(D, H, in_b, hipMemcpyHostToDevice, s));
+            if (!direct) HIPCHK(c, hipMemcpyAsync(D, H, in_b, hipMemcpyHostToDevice, s));
             rc0 = encode_device_locked(c, D + in_text - text_off[0], (const int64_t*)D, is_pair ? D + in_pair - pair_off[0] : nullptr,
                                        is_pair ? (const int64_t*)(D + in_poff) : nullptr, n_docs, max_len, flags, E, (int32_t*)(D + o_ids),
                                        (int32_t*)(D + o_mask), is_pair ? (int32_t*)(D + o_tt) : nullptr, is_pair ? (int32_t*)(D + o_seq) : nullptr,
                                        (int64_t*)(D + o_row), is_pair ? (int32_t*)(D + o_plen) : nullptr, (int32_t*)(D + o_nreal),
                                        is_pair ? (int32_t*)(D + o_status) : nullptr, text_off, pair_off);
             if (rc0) return rc0;
-            HIPCHK(c, hipMemcpyAsync(H + o_row, D + o_row, o_end - o_row, hipMemcpyDeviceToHost, s));
+            if (!direct) HIPCHK(c, hipMemcpyAsync(H + o_row, D + o_row, o_end - o_row, hipMemcpyDeviceToHost, s));
             if ((rc0 = sync_locked(c))) return rc0;
             int64_t total = n_docs * (int64_t)max_len;
             if (!dense) {

@@ -54,6 +54,8 @@ struct GzOptions {
     // ---- which kernels a call takes
     int32_t small = 1;                // 1: small dense / ragged batches in ONE launch (gz_small_kernel); 0: everything through the kernel pipeline
     int32_t small_wgs = 768;          // workgroups the one-launch kernel aims for
+    int32_t host_direct = 4096;       // host calls whose inputs and outputs both fit this many bytes are computed straight out of / into the pinned
+                                      // staging block (the kernels read and write host memory over the bus: no copy in, no copy back); 0: never
     int32_t assemble = 3;             // row writer of dense single texts: 3 gz_rows1_kernel, 2 the pair-mode kernel (rows through LDS), 1 the ragged layouts' scatter kernel
     int32_t word_table = 1;           // 0: every word through the merge loop (as GZ_NO_WORD_TABLE on every call)
     int32_t pp_fused = 1;             // 0: the text pre-pass filter by filter for every document

@@ -26,7 +26,7 @@ int gz_option_set(GzOptions& o, const char* key, int64_t v)
     if (!key) return GZ_E_INVALID;
     struct Key { const char* name; int32_t GzOptions::*p32; int64_t GzOptions::*p64; int64_t lo, hi; };
     static const Key keys[] = {
-        {"small", &GzOptions::small, nullptr, 0, 1}, {"small_wgs", &GzOptions::small_wgs, nullptr, 1, 1 << 20},
+        {"small", &GzOptions::small, nullptr, 0, 1}, {"small_wgs", &GzOptions::small_wgs, nullptr, 1, 1 << 20}, {"host_direct", &GzOptions::host_direct, nullptr, 0, 1 << 20},
         {"assemble", &GzOptions::assemble, nullptr, 1, 3}, {"word_table", &GzOptions::word_table, nullptr, 0, 1},
         {"pp_fused", &GzOptions::pp_fused, nullptr, 0, 1}, {"sub_batches", &GzOptions::sub_batches, nullptr, 1, 8},
         {"docs_per_wave", &GzOptions::docs_per_wave, nullptr, 0, 16}, {"side", &GzOptions::side, nullptr, 0, 1},

@@ -221,6 +221,8 @@ int64_t gz_limit(int which);
  * (value range; default):
  *   small (0..1; 1)            small batches in one launch; 0: everything through the kernel pipeline
  *   small_wgs (1..2^20; 768)   workgroups the one-launch kernel aims for
+ *   host_direct (0..2^20; 4096) host calls whose inputs and outputs both fit this many bytes are computed straight on the pinned staging
+ *                              block (no copy in, no copy back); 0: never
  *   assemble (1..3; 3)         row writer of dense single texts: 3 rows1, 2 the pair-mode kernel, 1 the ragged layouts' scatter kernel
  *   word_table (0..1; 1)       0: every word through the merge loop (as GZ_NO_WORD_TABLE on every call)
  *   pp_fused (0..1; 1)         0: the text pre-pass filter by filter for every document
