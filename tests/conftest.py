@@ -24,6 +24,12 @@ def pytest_configure(config):
         d = tempfile.mkdtemp(prefix="gz_table_cache_")
         os.environ["GZ_TABLE_CACHE"] = d
         atexit.register(shutil.rmtree, d, True)
+    # A GPU process that dies inside the runtime must leave its last words in the log: errors of the HIP runtime on stderr
+    # (AMD_LOG_LEVEL=1: errors only; read when the runtime loads), glibc's "corrupted ..." lines on stderr rather than on a terminal.
+    # (The main process too, not only the children of _run_child: round 5's abort came in the main process and pytest's capture
+    # kept whatever the runtime had said -- see _gpu_tests_write_to_the_real_stderr below.)
+    os.environ.setdefault("AMD_LOG_LEVEL", "1")
+    os.environ.setdefault("LIBC_FATAL_STDERR_", "1")
     # switches of the library a parent test asked for (GZ_TEST_SWITCHES="small=0,scan_multi=0": gz_switches.py -> gz_debug_set): set
     # as process-wide defaults before any context exists.  The library itself reads no switch from the environment.
     if os.environ.get("GZ_TEST_SWITCHES"):
@@ -45,3 +51,22 @@ def oracle_tables():
     import gz_oracle as O
     return O.Tables(open(os.path.join(DATA, "vocab.txt"), "rb").read(),
                     open(os.path.join(DATA, "bpe.codes"), "rb").read())
+
+
+@pytest.fixture(autouse=True)
+def _gpu_tests_write_to_the_real_stderr(request):
+    """GPU tests run with pytest's fd-level capture suspended: when the process is killed inside a native call (SIGABRT from the
+    HIP runtime, glibc or std::terminate) the captured text is never written out, and the one line that names the cause -- "Memory
+    access fault ...", "Queue ... aborting with error ...", "free(): invalid pointer", "terminate called after ..." -- is lost.
+    Before every such test a line with its name goes to stderr, so that whatever follows in the log belongs to a known test."""
+    if request.node.get_closest_marker("gpu") is None:
+        yield
+        return
+    capman = request.config.pluginmanager.getplugin("capturemanager")
+    if capman is None:
+        yield
+        return
+    with capman.global_and_fixture_disabled():
+        sys.stderr.write("\n[gpu test] %s\n" % request.node.nodeid)
+        sys.stderr.flush()
+        yield
