@@ -800,6 +800,29 @@ def secondary(ctx, tok, flags, args, cfg2):
                      "traffic_source": "profiles/r05_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, summed over the "
                                        "launch's kernels; reads not corrected for the gfx950 half-count)" if traffic else
                                        "none for this build (profiles/r05_pmc_traffic.json absent or taken on other kernel sources)"}}
+    # ---- the same documents WITHOUT padding (max_len=None, the reference's default call: ragged rows + int64 row offsets): all kernels
+    # of the call by hipEvents, inputs / outputs resident
+    capu = R.in_bytes + 2 * R.n
+    d_ui, d_um, d_uo = ctx.alloc(4 * capu), ctx.alloc(4 * capu), ctx.alloc(8 * (R.n + 1))
+    uflags = _native.GZ_PADDING | _native.GZ_TRUNCATION | _native.GZ_MAX_LEN_NONE | _native.GZ_TIMING
+    ums = []
+    for _ in range(4):
+        ctx.encode_device(R.d_text, R.d_off, 0, 0, R.n, 0, uflags, capu, d_ui, d_um, d_row_off=d_uo, d_n_real=R.d_nreal, h_text_off=R.offs)
+        ctx.sync()
+        ums.append(ctx.timing()[3])
+    uro = np.empty(R.n + 1, dtype=np.int64); ctx.d2h(uro, d_uo)
+    for q in (d_ui, d_um, d_uo):
+        ctx.free(q)
+    u_ms = float(np.mean(ums[1:]))
+    u_algo = R.in_bytes + 8 * (R.n + 1) + 8 * int(uro[-1]) + 8 * (R.n + 1) + 4 * R.n       # text + offsets in; ids + mask + row offsets + n_real out
+    out["configs_2_roofline_run"]["unpadded_run"] = {
+        "what": "the same documents with max_len=None (ragged rows + int64 row offsets; a count pass, the scan, every row written once): all kernels of the call by hipEvents",
+        "kernel_ms_avg": round(u_ms, 4), "MB_per_s_kernel": round(R.in_bytes / u_ms / 1e3, 1), "tokens": int(uro[-1]),
+        "algorithmic_bytes": int(u_algo), "roofline_frac": round(u_algo / u_ms / 1e6 / HBM_PEAK_GBS, 5),
+        "verified": "row offsets ascend, total >= the dense run's %d real tokens (rows cut at max_len there); the rows themselves: "
+                    "tests/test_gpu_parity.py (whole arrays against the C oracle)" % n_tok}
+    if int(uro[-1]) < n_tok or np.any(np.diff(uro) < 2):
+        sys.exit("bench: the unpadded run of configs[2] yields %d tokens, the dense run %d" % (int(uro[-1]), n_tok))
     # ---- the same step with the whole-word tables off: every word through the merge loop
     k2 = R.kernel_ms(flags | _native.GZ_NO_WORD_TABLE, reps=3)
     out["merge_loop_only"] = {"kernel_ms_avg": round(k2, 4), "MB_per_s_kernel": round(R.in_bytes / k2 / 1e3, 1)}

@@ -83,6 +83,8 @@ struct gz_ctx {
     struct Pending {
         bool active = false;
         bool ragged = false;
+        bool ragged_direct = false;    // single texts without padding: count pass, scan, rows written once at their places (gz_rowsr_kernel)
+        int64_t text_bytes = 0;
         GzFinalizeArgs F{};
         bool pair = false;
         GzPairArgs P{};
@@ -264,13 +266,15 @@ int enqueue(gz_ctx* c)
         for (int tx = 0; tx < S.n_texts; ++tx)
             gz_launch_pipeline_text(c->opt, T, c->dev, S.X[tx], S.n_docs, p.use_words, (int32_t*)c->w_flags.p + 3, sk, c->side, c->ev_sf0[k & 1][tx], c->ev_sf[k & 1][tx], c->ev_sj[k & 1][tx],
                                     p.inputs_resident ? c->ev_sb[k & 1][tx] : nullptr);
-        gz_launch_assemble(c->opt, T, S, sk);
+        if (p.ragged_direct) gz_launch_rows_ragged(T, S, 0, p.text_bytes, sk);      // the row lengths
+        else gz_launch_assemble(c->opt, T, S, sk);
     }
     if (two) { HIPCHK(c, hipEventRecord(c->ev_join, c->stream2)); HIPCHK(c, hipStreamWaitEvent(s, c->ev_join, 0)); }
     if (p.timing) { p.t_slot = (int)(c->ring_n % gz_ctx::RING); HIPCHK(c, hipEventRecord(c->ring[p.t_slot][1], s)); c->ring_n++; }
     if (p.ragged) {
         gz_launch_rowscan(p.F, (int64_t*)c->w_rowlen.p, s);
-        gz_launch_finalize(c->dev, p.F, s);
+        if (p.ragged_direct) gz_launch_rows_ragged(T, p.subs[0], 1, p.text_bytes, s);     // the rows, at their places
+        else gz_launch_finalize(c->dev, p.F, s);
     }
     if (p.timing && (p.ragged || p.pair)) HIPCHK(c, hipEventRecord(c->ev[2], s));      // (dense single texts: nothing follows the row kernel)
     if (p.pair) gz_launch_pair(c->dev, p.P, s);
@@ -498,14 +502,21 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
     }
     int32_t* raw = nullptr;
     int32_t* n_raw = n_real;
+    // Rows without padding of single texts (max_len None, padding False) are counted first and then written once, at their final
+    // places (gz_rowsr_kernel); pairs and the padded ragged shapes go through the raw area and the finalize kernel.  (The option
+    // assemble < 3 keeps the raw-area path for these rows too: tests.)
+    const bool direct_ok = !dense && !is_pair && !S.pad_mode && c->opt.assemble >= 3;
+    const bool maybe_small = c->opt.small && h_text_off && n_docs <= (1 << 20) && text_bytes + pair_bytes <= (2ll << 20);
     if (!dense) {
-        const int64_t raw_elems = text_bytes + pair_bytes + (is_pair ? 4 : 2) * n_docs;
-        rc = ensure(c, c->w_raw, (size_t)raw_elems * 4 + 16); if (rc) return rc;
         rc = ensure(c, c->w_rowlen, (size_t)(n_docs + 1) * 8); if (rc) return rc;
-        raw = (int32_t*)c->w_raw.p;
-        // raw token counts live in a private buffer: n_real is rewritten by the finalize kernel
-        rc = ensure(c, c->w_status, (size_t)(n_docs + 1) * 4); if (rc) return rc;
-        n_raw = (int32_t*)c->w_status.p;
+        if (!direct_ok || maybe_small) {
+            const int64_t raw_elems = text_bytes + pair_bytes + (is_pair ? 4 : 2) * n_docs;
+            rc = ensure(c, c->w_raw, (size_t)raw_elems * 4 + 16); if (rc) return rc;
+            raw = (int32_t*)c->w_raw.p;
+            // raw token counts live in a private buffer: n_real is rewritten by the finalize kernel
+            rc = ensure(c, c->w_status, (size_t)(n_docs + 1) * 4); if (rc) return rc;
+            n_raw = (int32_t*)c->w_status.p;
+        }
     }
     p.keep_words = (flags & GZ_KEEP_WORDS) != 0;
     {
@@ -538,6 +549,9 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
             }
         }
     }
+    p.ragged_direct = direct_ok && !p.small;
+    p.text_bytes = text_bytes;
+    if (p.ragged_direct) n_raw = n_real;                       // (the count pass writes the row lengths where the caller wants them)
     p.subs.resize((size_t)nsub);
     for (int k = 0; k < nsub; ++k) {
         const int64_t lo = (int64_t)k * n_docs / nsub, hi = (int64_t)(k + 1) * n_docs / nsub;
@@ -548,6 +562,7 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
         S2.mask = attention_mask + (dense ? lo * (int64_t)max_len : 0);
         S2.raw = raw; S2.n_real = n_raw + lo;
         S2.docs_per_wave = docs_per_wave;
+        S2.row_off = row_off; S2.capacity = capacity; S2.error_flag = (int32_t*)c->w_flags.p + 1;
         for (int tx = 0; tx < S2.n_texts; ++tx) {
             const int64_t* cut = tx ? cutB : cutA;
             int rc2 = setup_text(c, c->tw[k & 1][tx], c->w_tiny[k & 7][tx], (tx ? pair : text) + cut[k], (tx ? pair_off : text_off) + lo,

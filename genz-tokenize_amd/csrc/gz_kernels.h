@@ -72,6 +72,8 @@ struct GzAsmArgs {
     int32_t dense, max_len;
     int32_t* ids; int32_t* mask; int32_t* raw; int32_t* n_real;
     int32_t docs_per_wave;
+    // gz_rowsr_kernel (single texts without padding): the rows' places (write pass), the caller's capacity and the flag raised beyond it
+    const int64_t* row_off; int64_t capacity; int32_t* error_flag;
 };
 
 // T_host: the host copy of the table descriptor (table sizes decide launch shapes)
@@ -88,6 +90,7 @@ void gz_launch_compact(const int32_t* rows, const uint32_t* off, int64_t n_rows,
 void gz_launch_expand(const void* compact, int bits, const uint32_t* off, int64_t n_rows, int32_t row_len, int32_t pad_id, int32_t* ids,
                       int32_t* mask, hipStream_t s);
 void gz_launch_assemble(const GzOptions& O, const GzDeviceTables* T_dev, const GzAsmArgs& A, hipStream_t s);
+void gz_launch_rows_ragged(const GzDeviceTables* T_dev, const GzAsmArgs& A, int pass, int64_t text_bytes, hipStream_t s);
 // small batches, one launch (gz_small.inc): G documents per workgroup, G <= GZ_SMALL_DOCS_PER_WG and every group of G
 // documents (A and B texts together) <= GZ_SMALL_DOC_BYTES.  poff == nullptr: single texts.  dense: rows of max_len into
 // ids / mask; else: unpadded rows into the raw area `ids` (document d at (bytes before d) + 2 d per text) and their

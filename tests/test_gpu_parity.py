@@ -1436,6 +1436,67 @@ def test_extreme_batch_shapes(tok, sampler):
     assert np.array_equal(np.diff(out["row_off"]), np.full(5000, 4))
 
 
+def test_unpadded_rows_are_counted_then_written_once(tok, sampler):
+    """Single texts without padding (max_len None, padding False) take gz_rowsr_kernel: a count pass, the scan, then every row
+    written once at its place.  Documents around both buffer sizes of its rounds (512 and 1 536 words / tokens), empty ones, ones
+    whose words all go through the merge loop (many pieces per word: more tokens than words), and ones far too long for a round
+    (the plain walk) -- in a batch of short documents (8 per wave, small buffers) and in a batch of long ones (1 per wave, large
+    buffers); against the plain-C restatement, with the whole-word tables on and off; n_real; and a capacity that is too small."""
+    import random
+    import gz_oracle_c as OC
+    from genz_tokenize import _native
+    from corpus import VOCAB_PATH, BPE_PATH
+    co = OC.COracle(open(VOCAB_PATH, "rb").read(), open(BPE_PATH, "rb").read())
+    r = random.Random(77)
+    text, offs, _ = corpus.config_corpus(3, n_docs=6000, seed=61, sampler=sampler)
+    raw = text.tobytes()
+    base = [raw[offs[i]:offs[i + 1]].decode("utf-8") for i in range(6000)]
+    words = " ".join(base[:400]).split()
+    def doc(nw, odd=0.0):
+        ws = [(w if r.random() >= odd else "".join(r.choice("qxzwkjfđâệ") for _ in range(r.choice([3, 7, 12, 18])))) for w in (r.choice(words) for _ in range(nw))]
+        return " ".join(ws)
+    special = [doc(n, o) for n in (0, 1, 62, 63, 64, 65, 300, 480, 505, 510, 511, 512, 513, 600, 1000, 1500, 1530, 1534, 1535, 1536, 1537, 1600, 4000, 9000)
+               for o in (0.0, 0.5, 1.0)]
+    for kind in ("short", "long"):
+        docs = list(base[:3000]) if kind == "short" else [doc(r.choice([200, 400, 700, 900]), r.choice([0.0, 0.1])) for _ in range(600)]
+        for k, d in enumerate(special):
+            docs.insert((k * 37) % len(docs), d)
+        docs += ["", "", "a", ""]
+        t, to = OC._pack(docs)
+        t = np.ascontiguousarray(t); to = np.ascontiguousarray(to, dtype=np.int64)
+        assert (kind == "long") == (int(to[-1]) // len(docs) > 1024)
+        for ml, pad, tr in ((None, True, True), (50, False, True)):
+            ids, mask, _, _, row, _, _ = co.call_packed(t, to, max_len=ml, padding=pad, truncation=tr)
+            lens = np.diff(row)
+            for wt in (True, False):
+                out = tok.encode_packed(t, to, max_len=ml, padding=pad, truncation=tr, word_table=wt)
+                ro = np.asarray(out["row_off"], np.int64)
+                assert np.array_equal(np.diff(ro), lens)
+                assert np.array_equal(out["input_ids"].reshape(-1)[:row[-1]], ids[:row[-1]])
+                assert np.array_equal(out["attention_mask"].reshape(-1)[:row[-1]], mask[:row[-1]])
+                assert np.array_equal(np.asarray(out["n_real"]), lens)
+        # a capacity one entry short: GZ_E_CAPACITY, nothing written
+        ctx = tok._ctx
+        n = len(docs); total = int(row[-1])
+        d_t = ctx.alloc(len(t) + 64); ctx.h2d(d_t, t)
+        d_o = ctx.alloc(8 * (n + 1)); ctx.h2d(d_o, to)
+        d_i, d_m, d_r, d_ro = ctx.alloc(4 * total), ctx.alloc(4 * total), ctx.alloc(4 * n), ctx.alloc(8 * (n + 1))
+        fill = np.full(total, 0x5A5A5A5A, dtype=np.int32)
+        ctx.h2d(d_i, fill); ctx.h2d(d_m, fill)
+        with pytest.raises(_native.GzError) as e:
+            ctx.encode_device(d_t, d_o, 0, 0, n, 0, _native.GZ_MAX_LEN_NONE, total - 1, d_i, d_m, d_row_off=d_ro, d_n_real=d_r, h_text_off=to)
+            ctx.sync()
+        assert e.value.code == _native.GZ_E_CAPACITY
+        got = np.empty(total, np.int32); ctx.d2h(got, d_i)
+        assert np.all(got == 0x5A5A5A5A)
+        ctx.encode_device(d_t, d_o, 0, 0, n, 0, _native.GZ_MAX_LEN_NONE, total, d_i, d_m, d_row_off=d_ro, d_n_real=d_r, h_text_off=to)
+        ctx.sync()
+        ctx.d2h(got, d_i)
+        assert np.array_equal(got, ids[:total])
+        for q in (d_t, d_o, d_i, d_m, d_r, d_ro):
+            ctx.free(q)
+
+
 def test_chained_device_calls(tok, sampler):
     """Dense calls with host offsets are enqueued behind one another without a host sync (same workspace, stream order):
     five different batches of growing and shrinking size, chained, must each equal their stand-alone result."""

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Small driver for rocprofv3 (kernel trace or --pmc passes): encodes a cfg-3 corpus a few times through the
-device entry point.  No torch.  usage: prof_run.py [n_docs] [iters] [cfg]"""
+device entry point.  No torch.  usage: prof_run.py [n_docs] [iters] [cfg]     (RAGGED=1: without padding, max_len=None)"""
 import os
 import sys
 
@@ -28,10 +28,20 @@ flags = _native.GZ_PADDING | _native.GZ_TRUNCATION | _native.GZ_TIMING
 if os.environ.get("NO_WORD_TABLE"):
     flags |= _native.GZ_NO_WORD_TABLE
 ms = []
+ragged = bool(os.environ.get("RAGGED"))              # RAGGED=1: the same documents without padding (max_len=None: ragged rows + row offsets)
+if ragged:
+    offs = np.ascontiguousarray(offs, dtype=np.int64)
+    cap = len(text) + 2 * n
+    ctx.free(d_ids); ctx.free(d_mask - moff)
+    d_ids = ctx.alloc(4 * cap); d_mask = ctx.alloc(4 * cap); d_row = ctx.alloc(8 * (n + 1))
+    flags |= _native.GZ_MAX_LEN_NONE
 for _ in range(iters):
-    ctx.encode_device(d_text, d_off, 0, 0, n, L, flags, n * L, d_ids, d_mask, d_n_real=d_nreal)
+    if ragged:
+        ctx.encode_device(d_text, d_off, 0, 0, n, 0, flags, cap, d_ids, d_mask, d_row_off=d_row, d_n_real=d_nreal, h_text_off=offs)
+    else:
+        ctx.encode_device(d_text, d_off, 0, 0, n, L, flags, n * L, d_ids, d_mask, d_n_real=d_nreal)
     ctx.sync()
-    ms.append(ctx.timing()[0])
+    ms.append(ctx.timing()[3 if ragged else 0])
 nr = np.empty(n, dtype=np.int32); ctx.d2h(nr, d_nreal)
 print("docs", n, "bytes", len(text), "tokens", int(nr.sum()), "kernel ms", [round(x, 3) for x in ms],
       "MB/s", round(len(text) / min(ms) / 1e3, 1))

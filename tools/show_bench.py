@@ -11,9 +11,11 @@ for k in ("headline_host_paths", "merge_loop_only", "oov_sensitivity", "configs_
         print(k, {a: b for a, b in d[k].items() if a not in ("what", "workload")})
 if "configs_2_roofline_run" in d:
     print("configs_2", d["configs_2_roofline_run"]["timings"]["kernels_ms"], d["configs_2_roofline_run"]["timings"]["device_e2e_ms"],
-          d["configs_2_roofline_run"]["timings"]["python_e2e_ms"], d["configs_2_roofline_run"]["roofline"]["frac"])
+          d["configs_2_roofline_run"]["timings"]["python_e2e_ms"], d["configs_2_roofline_run"]["roofline"]["frac"],
+          "unpadded", d["configs_2_roofline_run"].get("unpadded_run", {}).get("kernel_ms_avg"))
 if "configs_4_long_docs" in d:
-    print("configs_4", d["configs_4_long_docs"]["kernel_ms_avg"], d["configs_4_long_docs"]["roofline"]["frac"])
+    print("configs_4", d["configs_4_long_docs"]["kernel_ms_avg"], d["configs_4_long_docs"]["roofline"]["frac"],
+          "unpadded", d["configs_4_long_docs"].get("unpadded_run", {}).get("kernel_ms_avg"))
 if "cpu_baseline" in d:
     print("cpu", d["cpu_baseline"]["value"], d["cpu_baseline"].get("all_cores", {}).get("value"))
 if "next_rows" in d:
