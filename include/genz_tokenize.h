@@ -182,7 +182,8 @@ int  gz_memcpy_d2h(gz_ctx *ctx, void *dst_host, const void *src_device, size_t b
 
 /* With GZ_TIMING: milliseconds (HIP events on the context's stream) of the kernels of the LAST encode call:
  * out[0] = the kernel pipeline of the call (split: brk / classify / scan / docw0; words; misses: scan / miss / miss_wide /
- * long; rows: rows1 | rows | assemble), out[1] = ragged finalize (row lengths, scan, copy), out[2] = pair type-id
+ * long; rows: rows1 | rows | assemble | rowsr's count pass), out[1] = ragged layouts: row lengths, scan, and the copy out of the raw
+ * area or -- single texts without padding -- the rows written at their places, out[2] = pair type-id
  * kernel, out[3] = whole call on the stream.  Unused slots are 0. */
 int  gz_timing(gz_ctx *ctx, double out_ms[4]);
 /* GZ_TIMING calls can be chained without gz_sync in between (a dense call followed by a call that brings host copies
@@ -223,7 +224,8 @@ int64_t gz_limit(int which);
  *   small_wgs (1..2^20; 768)   workgroups the one-launch kernel aims for
  *   host_direct (0..2^20; 4096) host calls whose inputs and outputs both fit this many bytes are computed straight on the pinned staging
  *                              block (no copy in, no copy back); 0: never
- *   assemble (1..3; 3)         row writer of dense single texts: 3 rows1, 2 the pair-mode kernel, 1 the ragged layouts' scatter kernel
+ *   assemble (1..3; 3)         row writer of dense single texts: 3 rows1, 2 the pair-mode kernel, 1 the ragged layouts' scatter kernel;
+ *                              single texts without padding: 3 counted, scanned, written once, < 3 through the raw area
  *   word_table (0..1; 1)       0: every word through the merge loop (as GZ_NO_WORD_TABLE on every call)
  *   pp_fused (0..1; 1)         0: the text pre-pass filter by filter for every document
  *   sub_batches (1..8; 1)      dense batches cut into document ranges on two streams
