@@ -93,6 +93,7 @@ struct gz_ctx {
         int use_words = 0;             // bit 0: whole-word table; bits 8..: timing diagnostics (switch `ablate`, diagnostic build)
         // small batches: ONE fused launch (gz_small_kernel) instead of the pipeline
         bool small = false, s_dense = true;
+        bool small_placed = false;     // ... and ragged rows of single texts without padding, ONE workgroup: places and rows made by that launch
         int small_G = 0;
         const uint8_t* s_text0 = nullptr; const int64_t* s_off = nullptr; int64_t s_base = 0, s_docs = 0;
         const uint8_t* s_pair0 = nullptr; const int64_t* s_poff = nullptr; int64_t s_pbase = 0;
@@ -258,8 +259,8 @@ int enqueue(gz_ctx* c)
     if (!p.subs.empty()) { int rs = need_side_streams(c, two); if (rs) return rs; }
     if (two) { HIPCHK(c, hipEventRecord(c->ev_fork, s)); HIPCHK(c, hipStreamWaitEvent(c->stream2, c->ev_fork, 0)); }
     if (p.small)
-        gz_launch_small(T, p.s_text0, p.s_off, p.s_base, p.s_pair0, p.s_poff, p.s_pbase, p.s_docs, p.small_G, p.s_dense ? 1 : 0, p.s_max_len,
-                        p.use_words, p.s_ids, p.s_mask, p.s_nreal, p.s_arena, s);
+        gz_launch_small(T, p.s_text0, p.s_off, p.s_base, p.s_pair0, p.s_poff, p.s_pbase, p.s_docs, p.small_G, p.s_dense ? 1 : p.small_placed ? 2 : 0, p.s_max_len,
+                        p.use_words, p.s_ids, p.s_mask, p.s_nreal, p.s_arena, p.F.row_off, p.F.capacity, (int32_t*)c->w_flags.p + 1, s);
     for (size_t k = 0; k < p.subs.size(); ++k) {
         hipStream_t sk = (k & 1) ? c->stream2 : s;
         const GzAsmArgs& S = p.subs[k];
@@ -271,7 +272,7 @@ int enqueue(gz_ctx* c)
     }
     if (two) { HIPCHK(c, hipEventRecord(c->ev_join, c->stream2)); HIPCHK(c, hipStreamWaitEvent(s, c->ev_join, 0)); }
     if (p.timing) { p.t_slot = (int)(c->ring_n % gz_ctx::RING); HIPCHK(c, hipEventRecord(c->ring[p.t_slot][1], s)); c->ring_n++; }
-    if (p.ragged) {
+    if (p.ragged && !p.small_placed) {
         gz_launch_rowscan(p.F, (int64_t*)c->w_rowlen.p, s);
         if (p.ragged_direct) gz_launch_rows_ragged(T, p.subs[0], 1, p.text_bytes, s);     // the rows, at their places
         else gz_launch_finalize(c->dev, p.F, s);
@@ -545,6 +546,12 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
                 if (is_pair) { p.s_pair0 = pair + cutB[0]; p.s_poff = pair_off; p.s_pbase = cutB[0]; }
                 p.s_dense = dense; p.s_max_len = max_len; p.s_arena = (int32_t*)W.mtok.p;
                 p.s_ids = dense ? input_ids : raw; p.s_mask = dense ? attention_mask : raw; p.s_nreal = dense ? n_real : n_raw;
+                // one workgroup holds the whole call (a single encode(), a handful of sentences) and the rows have no padding: it also
+                // places and writes them -- three launches less behind it
+                if (direct_ok && (n_docs + G - 1) / G == 1) {
+                    p.small_placed = true;
+                    p.s_ids = input_ids; p.s_mask = attention_mask; p.s_nreal = n_real;
+                }
                 nsub = 0;
             }
         }
