@@ -548,7 +548,7 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
                 p.s_ids = dense ? input_ids : raw; p.s_mask = dense ? attention_mask : raw; p.s_nreal = dense ? n_real : n_raw;
                 // one workgroup holds the whole call (a single encode(), a handful of sentences) and the rows have no padding: it also
                 // places and writes them -- three launches less behind it
-                if (direct_ok && (n_docs + G - 1) / G == 1) {
+                if (!dense && !S.pad_mode && c->opt.assemble >= 3 && (n_docs + G - 1) / G == 1) {       // (pairs too: gz_pair_kernel follows either way)
                     p.small_placed = true;
                     p.s_ids = input_ids; p.s_mask = attention_mask; p.s_nreal = n_real;
                 }

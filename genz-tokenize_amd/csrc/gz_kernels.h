@@ -96,7 +96,7 @@ void gz_launch_rows_ragged(const GzDeviceTables* T_dev, const GzAsmArgs& A, int 
 // ids / mask; else: unpadded rows into the raw area `ids` (document d at (bytes before d) + 2 d per text) and their
 // lengths into n_real.  arena: [text bytes + pair bytes + 32] words of scratch for very long words.
 constexpr int GZ_SMALL_DOC_BYTES = 4096, GZ_SMALL_DOCS_PER_WG = 64;
-// layout 2 (single texts without padding, ONE workgroup: (n_docs + G - 1) / G == 1): the kernel also makes row_off[n_docs + 1] and writes
+// layout 2 (rows without padding, ONE workgroup: (n_docs + G - 1) / G == 1): the kernel also makes row_off[n_docs + 1] and writes
 // ids / mask at their final places (no rowlen / scan / finalize behind it); beyond `capacity` entries: *error_flag = 1, nothing written
 void gz_launch_small(const GzDeviceTables* T_dev, const uint8_t* text0, const int64_t* off, int64_t base, const uint8_t* pair0, const int64_t* poff,
                      int64_t pbase, int64_t n_docs, int G, int layout /* 1 dense, 0 raw area, 2 placed */, int max_len, int use_words, int32_t* ids,
