@@ -1495,6 +1495,33 @@ def test_unpadded_rows_are_counted_then_written_once(tok, sampler):
         assert np.array_equal(got, ids[:total])
         for q in (d_t, d_o, d_i, d_m, d_r, d_ro):
             ctx.free(q)
+    # the one-launch kernel places the rows of a call that ONE workgroup holds (layout 2): the same capacity rule there, single and paired
+    docs = ["xin chào việt nam", "", "sinh_viên công_nghệ qxzwk"]
+    t, to = OC._pack(docs)
+    t = np.ascontiguousarray(t); to = np.ascontiguousarray(to, dtype=np.int64)
+    for pair in (False, True):
+        ids, mask, _, _, row, _, _ = co.call_packed(t, to, t if pair else None, to if pair else None, None, True, True)
+        total = int(row[-1])
+        out = tok.encode_packed(t, to, t, to, max_len=None) if pair else tok.encode_packed(t, to, max_len=None)
+        assert np.array_equal(np.asarray(out["row_off"], np.int64), row) and np.array_equal(out["input_ids"].reshape(-1)[:total], ids[:total])
+        assert np.array_equal(out["attention_mask"].reshape(-1)[:total], mask[:total])
+        n = len(docs)
+        d_t = ctx.alloc(len(t) + 64); ctx.h2d(d_t, t)
+        d_o = ctx.alloc(8 * (n + 1)); ctx.h2d(d_o, to)
+        bufs = [ctx.alloc(4 * total + 64) for _ in range(4)] + [ctx.alloc(8 * (n + 1)), ctx.alloc(8 * n + 8), ctx.alloc(4 * n + 4), ctx.alloc(4 * n + 4)]
+        d_i, d_m, d_tt, d_sq, d_ro, d_pl, d_r, d_st = bufs
+        fill = np.full(total, 0x5A5A5A5A, dtype=np.int32)
+        ctx.h2d(d_i, fill)
+        kw = dict(d_tt=d_tt, d_seq=d_sq, d_pair_len=d_pl, d_status=d_st, h_pair_off=to) if pair else {}
+        with pytest.raises(_native.GzError) as e:
+            ctx.encode_device(d_t, d_o, d_t if pair else 0, d_o if pair else 0, n, 0, _native.GZ_MAX_LEN_NONE, total - 1, d_i, d_m,
+                              d_row_off=d_ro, d_n_real=d_r, h_text_off=to, **kw)
+            ctx.sync()
+        assert e.value.code == _native.GZ_E_CAPACITY
+        got = np.empty(total, np.int32); ctx.d2h(got, d_i)
+        assert np.all(got == 0x5A5A5A5A)
+        for q in [d_t, d_o] + bufs:
+            ctx.free(q)
 
 
 def test_chained_device_calls(tok, sampler):
