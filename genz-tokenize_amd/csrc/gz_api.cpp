@@ -1552,6 +1552,18 @@ uint32_t dec_flags(const std::string& w)
     return f;
 }
 
+// the table entry of a word whose bytes are (or would be) at `off` of the byte arena
+GzDecEntry dec_entry_of(const std::string& w, size_t off)
+{
+    GzDecEntry e{dec_flags(w), {(uint32_t)off, 0u, 0u}};
+    if (w.size() <= 12 && !(e.len_flags & GZ_DEC_INNER)) {
+        e.len_flags |= GZ_DEC_INLINE;
+        e.w[0] = 0;
+        for (size_t k = 0; k < w.size(); ++k) e.w[k >> 2] |= (uint32_t)(uint8_t)w[k] << (8 * (k & 3));
+    }
+    return e;
+}
+
 int dec_set_unk(gz_ctx* c, const uint8_t* unk, int32_t unk_len)
 {
     if (unk_len < 0 || (size_t)unk_len > GZ_DEC_UNK_MAX) return fail(c, GZ_E_LIMIT, "unk string longer than %zu bytes", GZ_DEC_UNK_MAX);
@@ -1559,7 +1571,7 @@ int dec_set_unk(gz_ctx* c, const uint8_t* unk, int32_t unk_len)
     if (c->dec_unk_set && u == c->dec_unk) return GZ_OK;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if (unk_len) HIPCHK(c, hipMemcpy((uint8_t*)c->t_dec_bytes.p + c->dec_bytes_len, unk, (size_t)unk_len, hipMemcpyHostToDevice));
-    GzDecEntry e{(uint32_t)c->dec_bytes_len, dec_flags(u)};
+    const GzDecEntry e = dec_entry_of(u, c->dec_bytes_len);
     HIPCHK(c, hipMemcpy((GzDecEntry*)c->t_dec_entries.p + c->dec_n_ids, &e, sizeof e, hipMemcpyHostToDevice));
     c->dec_unk = u;
     c->dec_unk_set = true;
@@ -1601,16 +1613,16 @@ int gz_decoder_snapshot(gz_ctx* c)
     for (int32_t id : c->host.enc_ids) if (id + 1 > n_ids) n_ids = id + 1;
     std::vector<int64_t> last((size_t)n_ids, -1);
     for (size_t i = 0; i < c->host.enc_ids.size(); ++i) if (c->host.enc_ids[i] >= 0) last[(size_t)c->host.enc_ids[i]] = (int64_t)i;
-    std::vector<GzDecEntry> ent((size_t)n_ids + 1, GzDecEntry{0, GZ_DEC_ABSENT});
+    std::vector<GzDecEntry> ent((size_t)n_ids + 1, GzDecEntry{GZ_DEC_ABSENT, {0u, 0u, 0u}});
     std::string bytes;
     for (int32_t id = 0; id < n_ids; ++id) {
         if (last[(size_t)id] < 0) continue;
         const std::string& w = c->host.enc_words[(size_t)last[(size_t)id]];
         if (w.size() > GZ_DEC_LEN_MASK || bytes.size() + w.size() > 0xFFFF0000ull) return fail(c, GZ_E_LIMIT, "vocabulary too large for the decoder arena");
-        ent[(size_t)id] = GzDecEntry{(uint32_t)bytes.size(), dec_flags(w)};
+        ent[(size_t)id] = dec_entry_of(w, bytes.size());
         bytes += w;
     }
-    ent[(size_t)n_ids] = GzDecEntry{(uint32_t)bytes.size(), 0};
+    ent[(size_t)n_ids] = GzDecEntry{GZ_DEC_INLINE, {0u, 0u, 0u}};                  // (the unk string: set per call, dec_set_unk)
     int rc;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if ((rc = ensure(c, c->t_dec_entries, ent.size() * sizeof(GzDecEntry)))) return rc;

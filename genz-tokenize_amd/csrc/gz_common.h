@@ -211,10 +211,13 @@ void gz_ph_build(size_t n, void (*hashes)(const void* ctx, size_t i, uint32_t k1
 
 // Host-side result of the loader (tokenize.py:31-57) and of the table build.
 // ---- decoder snapshot (id -> word bytes), tokenize.py:40 -------------------------------------------------------------
-struct GzDecEntry { uint32_t off; uint32_t len_flags; };       // len:24 | flags
+// 16 bytes per id, ONE load: len:24 | flags, then -- GZ_DEC_INLINE: words of <= 12 bytes without an inner "@@ ", nearly all --
+// the word's bytes themselves (zero padded), else w[0] = the word's offset in the byte arena
+struct GzDecEntry { uint32_t len_flags; uint32_t w[3]; };
 constexpr uint32_t GZ_DEC_LEN_MASK  = 0x00FFFFFFu;
 constexpr uint32_t GZ_DEC_ENDS_ATAT = 0x01000000u;              // the word ends in "@@"
 constexpr uint32_t GZ_DEC_INNER     = 0x02000000u;              // the word contains "@@ " inside: filter byte by byte
+constexpr uint32_t GZ_DEC_INLINE    = 0x04000000u;              // the word's bytes are in the entry
 constexpr uint32_t GZ_DEC_ABSENT    = 0xFFFFFFFFu;              // no word has this id
 struct GzDecTable {
     const GzDecEntry* entries;      // [n_ids + 1]; entries[n_ids] = the unk string of the current call
