@@ -1088,10 +1088,12 @@ def test_gather_rows_refuses_bad_arguments_before_opening_a_group(tok):
     ctx.free(d_src); ctx.free(d_dst)
 
 
-def test_compact_expand_round_trip(tok, sampler):
-    """The exchange step's compact form: rows without padding -> padding and mask rebuilt == the dense output."""
+@pytest.mark.parametrize("n_docs", [5000, 40003])
+def test_compact_expand_round_trip(tok, sampler, n_docs):
+    """The exchange step's compact form: rows without padding -> padding and mask rebuilt == the dense output.  (40 003 rows: the row
+    offsets come from the scan over many workgroups, as for a shard; 5 000: from the one-workgroup scan.)"""
     ctx = tok._ctx
-    text, offs, L = corpus.config_corpus(3, n_docs=5000, seed=31, sampler=sampler)
+    text, offs, L = corpus.config_corpus(3, n_docs=n_docs, seed=31, sampler=sampler)
     out = tok.encode_packed(text, offs, max_len=L)
     ids, mask, n_real = out["input_ids"], out["attention_mask"], out["n_real"]
     n = len(offs) - 1
