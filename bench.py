@@ -344,7 +344,7 @@ def main():
 
     import corpus
     from genz_tokenize import Tokenize, _native
-    from genz_tokenize.distributed import rank_shards, global_shard_id, GatherRound, csr_words
+    from genz_tokenize.distributed import rank_shards, global_shard_id, GatherRound, csr_words, block_words
     import gz_switches
     switched = gz_switches.apply(args.switches) if args.switches else gz_switches.apply()      # (before any context exists)
     tok = Tokenize(device=device)
@@ -368,8 +368,8 @@ def main():
                       for _ in range(nset)]
         if gather:
             for st in sh["sets"]:
-                # this rank's message of the exchange step: [n_real | the rows' real entries] (worst case: every row full)
-                st["block"] = ctx.alloc(4 * (sh["n"] + csr_words(sh["n"] * L, xbits)))
+                # this rank's message of the exchange step: [n_real | first | the rows' real entries] (worst case: every row full)
+                st["block"] = ctx.alloc(4 * block_words(sh["n"], sh["n"] * L, xbits))
         shards.append(sh)
     m = len(shards)                                               # shards per rank (the same on every rank: 8 / G)
     n = shards[0]["n"]
@@ -386,7 +386,7 @@ def main():
             ctx.comm_init(uid[0], rank, world)
         if rank == 0:
             for r in rounds:
-                r["plan"].capacity = world * (n + csr_words(n * L, xbits))
+                r["plan"].capacity = world * block_words(n, n * L, xbits)
                 r["recv"] = ctx.alloc(4 * r["plan"].capacity)
 
     def gloo_gatherv(d_src, my_words, d_dst, words):
@@ -420,21 +420,22 @@ def main():
     size_in = torch.zeros(1, dtype=torch.int64) if dist is not None else None
     size_out = torch.zeros(world, dtype=torch.int64) if dist is not None else None
 
-    def exchange(j, st):
-        """Exchange step of local shard j: every rank sends the shard's rows WITHOUT the padding -- ONE block [row lengths | the
-        rows' real entries] -- straight to rank 0 over its own xGMI link (one grouped ncclSend / ncclRecv per shard).  The host
-        waits for the compact kernel of THIS shard only (the next shard's kernels are already queued on the main stream), then
-        the ranks tell each other their block sizes over gloo (ONE all-gather into a preallocated int64 tensor: no pickling)."""
+    def exchange(j, st, back=None):
+        """Exchange step of local shard j: every rank sends the shard's rows WITHOUT the padding -- ONE block [row lengths | first
+        entries | the rows' real entries], written by the shard's own row kernel (gz_encode_emit_block) -- straight to rank 0 over
+        its own xGMI link (one grouped ncclSend / ncclRecv per shard).  The host waits for the kernels of THIS shard only (the next
+        shards' kernels are already queued on the main stream) to learn the block's size, then the ranks tell each other their
+        block sizes over gloo (ONE all-gather into a preallocated int64 tensor: no pickling)."""
         r = rounds[j]
         plan = r["plan"]
         t_a = time.perf_counter()
-        total = ctx.compact_block(st["ids"], st["nreal"], n, L, st["block"], bits=xbits)
+        total = ctx.block_total(LOOK if back is None else back)
         t_b = time.perf_counter()
         size_in[0] = int(total)
         dist.all_gather_into_tensor(size_out, size_in)
         t_c = time.perf_counter()
         plan.announce(size_out.tolist())                          # entries per rank -> words per rank (n_real header not included)
-        words = [n + w for w in plan.words]                      # a block = n row lengths + the entries
+        words = [2 * n + w for w in plan.words]                  # a block = n row lengths + n first entries + the entries
         if rank == 0 and sum(words) > plan.capacity:
             sys.exit("bench: receive buffer too small (cannot happen: it holds the worst case)")
         if gloo:
@@ -459,6 +460,8 @@ def main():
         for _ in range(k_steps):
             for j, sh in enumerate(shards):
                 st = sh["sets"][step_no[0] % len(sh["sets"])]
+                if gather:
+                    ctx.encode_emit_block(st["block"], xbits)      # the call's row kernel also writes the shard's block
                 ctx.encode_device(sh["d_text"], sh["d_off"], 0, 0, sh["n"], L, flags, sh["n"] * L, st["ids"], st["mask"],
                                   d_n_real=st["nreal"], h_text_off=sh["offs"])
                 if gather:
@@ -469,7 +472,7 @@ def main():
             step_no[0] += 1
         while waiting:
             ctx.exchange_select(len(waiting) - 1)
-            exchange(*waiting.popleft())
+            exchange(*waiting.popleft(), back=len(waiting))      # (after the pop: this many calls came behind the one whose block leaves)
         # the launches were enqueued back to back (no host sync between them unless the exchange needs one); this
         # synchronises and reads the hipEvent pairs recorded around every call's launches on the library's stream
         hist = ctx.timing_history(1024)
@@ -649,13 +652,15 @@ def main():
         if switched:
             out["switches"] = dict(switched)                         # (diagnostic run: gz_debug_set pairs in force)
         if xinfo is not None:
-            host_ms = xinfo[0] + xinfo[1] + xinfo[2]
+            host_ms = xinfo[1] + xinfo[2]                            # the host's own part: size exchange + the gather's enqueue
             out["exchange"] = {
-                "what": "one exchange step = one shard's block [int32 row lengths | %d-bit real entries] from every peer to rank 0; per step, "
+                "what": "one exchange step = one shard's block [int32 row lengths | uint32 first entries | %d-bit real entries] -- made by the "
+                        "shard's own encode call, behind its kernels (gz_encode_emit_block) -- from every peer to rank 0; per step, "
                         "mean over a rank's steps inside the timed region, MAX over the ranks" % xbits,
                 "transport": "gloo rehearsal (D2H -> send/recv -> H2D)" if gloo else "RCCL grouped ncclSend/ncclRecv",
                 "bytes_per_peer": int(xinfo[5]),
-                "compact_sync_ms": round(xinfo[0], 4),          # host blocked until THIS shard's compact kernel has its total
+                "compact_sync_ms": round(xinfo[0], 4),          # gz_block_total: the host waits until THIS shard's kernels and its block are done (two calls are queued behind it: in
+                                                                # the steady state this is the GPU's pace, one launch period -- not host work)
                 "size_exchange_ms": round(xinfo[1], 4),         # one gloo all_gather_into_tensor of an int64
                 "gather_enqueue_ms": round(xinfo[2], 4),        # host time of gz_gather_rows (gloo rehearsal: the whole transfer)
                 "gather_enqueue_to_done_ms": None if gloo else round(xinfo[3], 4),     # hipEvents on the exchange stream
@@ -663,8 +668,8 @@ def main():
                 "link_GB_per_s_per_peer": None if (gloo or xinfo[3] <= 0) else round(xinfo[5] / (xinfo[3] * 1e-3) / 1e9, 2),
                 "host_control_ms": round(host_ms, 4),
                 "kernels_ms_per_step": round(k_ms, 4),
-                # the exchange of shard k runs under the kernels of shard k + 1: it is hidden while both the host's part and the
-                # transfer stay under one launch's kernels
+                # the exchange of shard k runs under the kernels of shards k + 1, k + 2: it is hidden while both the host's own part and
+                # the transfer stay under one launch's kernels
                 "hidden_under_kernels": bool(host_ms < k_ms and (gloo or xinfo[3] < k_ms)),
             }
         out.update(sec)

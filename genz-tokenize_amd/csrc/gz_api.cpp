@@ -84,6 +84,8 @@ struct gz_ctx {
         bool active = false;
         bool ragged = false;
         bool ragged_direct = false;    // single texts without padding: count pass, scan, rows written once at their places (gz_rowsr_kernel)
+        int32_t* emit_block = nullptr; int32_t emit_bits = 0, emit_slot = 0;      // the call also leaves its exchange block ...
+        int32_t* emit_rows = nullptr; int32_t* emit_nreal = nullptr; int64_t emit_n = 0; int32_t emit_len = 0;
         int64_t text_bytes = 0;
         GzFinalizeArgs F{};
         bool pair = false;
@@ -129,6 +131,11 @@ struct gz_ctx {
     // exchange step (compact / gather / expand) on its own stream, so that it overlaps the next call's kernels
     hipStream_t xstream = nullptr;
     hipEvent_t ev_tok[4] = {nullptr, nullptr, nullptr, nullptr};   // end of the last four encode calls
+    // exchange block made by the encode call itself (gz_encode_emit_block arms the next call): the block of the last four calls --
+    // its number of entries goes through w_flags[8 + slot] into h_pick's tail (uint32 56 + slot) before ev_blk[slot]
+    int32_t* emit_block = nullptr; int32_t emit_bits = 0;
+    hipEvent_t ev_blk[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool blk_valid[4] = {false, false, false, false};
     hipEvent_t ev_x = nullptr;                                       // last exchange operation issued
     // gz_gather_rows, timed: a pair of events on the exchange stream around every gather (gz_exchange_timing_history)
     static constexpr int XRING = 64;
@@ -272,6 +279,22 @@ int enqueue(gz_ctx* c)
     }
     if (two) { HIPCHK(c, hipEventRecord(c->ev_join, c->stream2)); HIPCHK(c, hipStreamWaitEvent(s, c->ev_join, 0)); }
     if (p.timing) { p.t_slot = (int)(c->ring_n % gz_ctx::RING); HIPCHK(c, hipEventRecord(c->ring[p.t_slot][1], s)); c->ring_n++; }
+    if (p.emit_block) {
+        uint32_t* cur = (uint32_t*)c->w_flags.p + 8 + p.emit_slot;
+        {
+            // the block from the call's dense rows, right behind its kernels on the SAME stream: the row lengths, their scan, the compact
+            // kernel.  (On the exchange stream -- beside the next call's kernels -- the same work stretched those kernels by more than it
+            // takes here; a row kernel that writes the block itself was tried twice, r05_ab_variants.txt series 13.)
+            uint32_t* off = (uint32_t*)c->w_rowoff32.p;
+            if (p.emit_n) HIPCHK(c, hipMemcpyAsync(p.emit_block, p.emit_nreal, (size_t)p.emit_n * 4, hipMemcpyDeviceToDevice, s));
+            gz_launch_row_offsets(p.emit_nreal, p.emit_n, off, s);
+            gz_launch_compact(p.emit_rows, off, p.emit_n, p.emit_len, p.emit_block + 2 * p.emit_n, p.emit_bits, (uint32_t*)(p.emit_block + p.emit_n), s);
+            HIPCHK(c, hipMemcpyAsync(cur, off + p.emit_n, 4, hipMemcpyDeviceToDevice, s));
+        }
+        HIPCHK(c, hipMemcpyAsync(reinterpret_cast<uint32_t*>(c->h_pick) + 56 + p.emit_slot, cur, 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipEventRecord(c->ev_blk[p.emit_slot], s));
+        c->blk_valid[p.emit_slot] = true;
+    } else c->blk_valid[c->enc_seq & 3] = false;
     if (p.ragged && !p.small_placed) {
         gz_launch_rowscan(p.F, (int64_t*)c->w_rowlen.p, s);
         if (p.ragged_direct) gz_launch_rows_ragged(T, p.subs[0], 1, p.text_bytes, s);     // the rows, at their places
@@ -576,6 +599,15 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
                                  cut[k + 1] - cut[k], S2.n_docs, c->stream, S2.X[tx]);
             if (rc2) return rc2;
         }
+    }
+    if (c->emit_block) {
+        // the call's exchange block: [n_real[n] | first[n] | entries]
+        if (!dense) return fail(c, GZ_E_INVALID, "gz_encode_emit_block needs a dense call (padding, truncation, max_len >= 1)");
+        p.emit_block = c->emit_block; p.emit_bits = c->emit_bits; p.emit_slot = (int32_t)(c->enc_seq & 3);
+        p.emit_rows = input_ids; p.emit_nreal = n_real; p.emit_n = n_docs; p.emit_len = max_len;
+        c->emit_block = nullptr;
+        if (!c->ev_blk[p.emit_slot]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_blk[p.emit_slot], hipEventDisableTiming));
+        if ((rc = ensure(c, c->w_rowoff32, (size_t)(n_docs + 2) * 4))) return rc;       // (the fallback's scan)
     }
     if (!dense) {
         p.ragged = true;
@@ -1388,7 +1420,7 @@ int gz_encode_batch_csr(gz_ctx* c, const uint8_t* text, const int64_t* text_off,
         gz_launch_assemble(c->opt, T, A, s);
         uint32_t* off32 = (uint32_t*)c->w_csr_off32.p;
         gz_launch_row_offsets(A.n_real, A.n_docs, off32, s);
-        gz_launch_compact(A.ids, off32, A.n_docs, max_len, (uint8_t*)c->w_csr_comp.p + (size_t)bound[(size_t)k] * esz, bits, s);
+        gz_launch_compact(A.ids, off32, A.n_docs, max_len, (uint8_t*)c->w_csr_comp.p + (size_t)bound[(size_t)k] * esz, bits, nullptr, s);
         HIPCHK(c, hipMemcpyAsync(&c->h_tot[k], off32 + A.n_docs, 4, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipEventRecord(c->ev_done[k], s));
     }
@@ -1878,7 +1910,7 @@ void gz_dlpack_capsule_destructor(void* capsule)
 // ---- compact rows for the exchange step -----------------------------------------------------------------------------
 namespace {
 int compact_impl(gz_ctx* c, const int32_t* rows_dev, const int32_t* n_real_dev, int64_t n_rows, int32_t row_len, void* out_dev,
-                 int bits, int64_t* total_host)
+                 int bits, int64_t* total_host, uint32_t* first_dev = nullptr)
 {
     if (!c || !rows_dev || !n_real_dev || !out_dev || !total_host || n_rows < 0 || row_len <= 0)
         return c ? fail(c, GZ_E_INVALID, "bad arguments") : GZ_E_INVALID;
@@ -1890,7 +1922,7 @@ int compact_impl(gz_ctx* c, const int32_t* rows_dev, const int32_t* n_real_dev, 
     uint32_t* off = (uint32_t*)c->w_rowoff32.p;
     if ((rc = x_begin(c))) return rc;
     gz_launch_row_offsets(n_real_dev, n_rows, off, c->xstream);
-    gz_launch_compact(rows_dev, off, n_rows, row_len, out_dev, bits, c->xstream);
+    gz_launch_compact(rows_dev, off, n_rows, row_len, out_dev, bits, first_dev, c->xstream);
     uint32_t* total = reinterpret_cast<uint32_t*>(c->h_pick) + 60;           // pinned (h_pick is 256 bytes; its tail is free)
     HIPCHK(c, hipMemcpyAsync(total, off + n_rows, 4, hipMemcpyDeviceToHost, c->xstream));
     if ((rc = x_end(c))) return rc;
@@ -1900,7 +1932,7 @@ int compact_impl(gz_ctx* c, const int32_t* rows_dev, const int32_t* n_real_dev, 
     return GZ_OK;
 }
 int expand_impl(gz_ctx* c, const void* compact_dev, int bits, const int32_t* n_real_dev, int64_t n_rows, int32_t row_len,
-                int32_t* ids_dev, int32_t* mask_dev)
+                int32_t* ids_dev, int32_t* mask_dev, const uint32_t* first_dev = nullptr /* a block's own array: no scan */)
 {
     if (!c || !compact_dev || !n_real_dev || !ids_dev || !mask_dev || n_rows < 0 || row_len <= 0)
         return c ? fail(c, GZ_E_INVALID, "bad arguments") : GZ_E_INVALID;
@@ -1908,11 +1940,14 @@ int expand_impl(gz_ctx* c, const void* compact_dev, int bits, const int32_t* n_r
     if (!c->have_tables) return fail(c, GZ_E_NOTABLES, "gz_load_tables has not been called");
     HIPCHK(c, hipSetDevice(c->device));
     int rc;
-    if ((rc = ensure(c, c->w_rowoff32, (size_t)(n_rows + 2) * 4))) return rc;
-    uint32_t* off = (uint32_t*)c->w_rowoff32.p;
+    const uint32_t* off = first_dev;
+    if (!off) {
+        if ((rc = ensure(c, c->w_rowoff32, (size_t)(n_rows + 2) * 4))) return rc;
+        off = (const uint32_t*)c->w_rowoff32.p;
+    }
     if ((rc = x_begin(c))) return rc;
-    gz_launch_row_offsets(n_real_dev, n_rows, off, c->xstream);
-    gz_launch_expand(compact_dev, bits, off, n_rows, row_len, c->dev.pad_id, ids_dev, mask_dev, c->xstream);
+    if (!first_dev) gz_launch_row_offsets(n_real_dev, n_rows, (uint32_t*)c->w_rowoff32.p, c->xstream);
+    gz_launch_expand(compact_dev, bits, off, n_real_dev, n_rows, row_len, c->dev.pad_id, ids_dev, mask_dev, c->xstream);
     if ((rc = x_end(c))) return rc;
     HIPCHK(c, hipGetLastError());
     return GZ_OK;
@@ -1940,6 +1975,27 @@ int gz_expand_rows16(gz_ctx* c, const uint16_t* compact_dev, const int32_t* n_re
     return expand_impl(c, compact_dev, 16, n_real_dev, n_rows, row_len, ids_dev, mask_dev);
 }
 
+int gz_encode_emit_block(gz_ctx* c, int32_t* block_dev, int32_t bits)
+{
+    if (!c || (bits != 16 && bits != 32)) return c ? fail(c, GZ_E_INVALID, "bad arguments") : GZ_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (block_dev && bits == 16 && (!c->have_tables || !ids_fit_16(c))) return fail(c, GZ_E_LIMIT, "the vocabulary has ids that do not fit 16 bits");
+    c->emit_block = block_dev; c->emit_bits = bits;              // (null: disarm)
+    return GZ_OK;
+}
+int gz_block_total(gz_ctx* c, int32_t back, int64_t* total_host)
+{
+    if (!c || !total_host || back < 0 || back > 2) return c ? fail(c, GZ_E_INVALID, "bad arguments") : GZ_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->enc_seq <= (uint64_t)back) return fail(c, GZ_E_INVALID, "no encode call %d calls back", back);
+    const int slot = (int)((c->enc_seq - 1 - (uint64_t)back) & 3);
+    if (!c->blk_valid[slot]) return fail(c, GZ_E_INVALID, "the encode call %d calls back emitted no block (gz_encode_emit_block before it)", back);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipEventSynchronize(c->ev_blk[slot]));
+    *total_host = reinterpret_cast<uint32_t*>(c->h_pick)[56 + slot];
+    return GZ_OK;
+}
+
 int gz_compact_block(gz_ctx* c, const int32_t* rows_dev, const int32_t* n_real_dev, int64_t n_rows, int32_t row_len, int32_t bits,
                      int32_t* block_dev, int64_t* total_host)
 {
@@ -1953,12 +2009,12 @@ int gz_compact_block(gz_ctx* c, const int32_t* rows_dev, const int32_t* n_real_d
         if (n_rows) HIPCHK(c, hipMemcpyAsync(block_dev, n_real_dev, (size_t)n_rows * 4, hipMemcpyDeviceToDevice, c->xstream));
         if ((rc = x_end(c))) return rc;
     }
-    return compact_impl(c, rows_dev, n_real_dev, n_rows, row_len, block_dev + n_rows, bits, total_host);
+    return compact_impl(c, rows_dev, n_real_dev, n_rows, row_len, block_dev + 2 * n_rows, bits, total_host, (uint32_t*)(block_dev + n_rows));
 }
 int gz_expand_block(gz_ctx* c, const int32_t* block_dev, int32_t bits, int64_t n_rows, int32_t row_len, int32_t* ids_dev, int32_t* mask_dev)
 {
     if (!c || !block_dev || n_rows < 0 || (bits != 16 && bits != 32)) return c ? fail(c, GZ_E_INVALID, "bad arguments") : GZ_E_INVALID;
-    return expand_impl(c, block_dev + n_rows, bits, block_dev, n_rows, row_len, ids_dev, mask_dev);
+    return expand_impl(c, block_dev + 2 * n_rows, bits, block_dev, n_rows, row_len, ids_dev, mask_dev, (const uint32_t*)(block_dev + n_rows));
 }
 
 // ---- multi-GPU exchange step --------------------------------------------------------------------------------------

@@ -86,9 +86,12 @@ void gz_launch_pipeline_text(const GzOptions& O, const GzDeviceTables* T_dev, co
                                                             bits are prepared on the side stream, under whatever s is still running */);
 void gz_launch_pick(const int64_t* off, const int64_t* off2, int64_t n_docs, int nsub, int64_t* out /* 2*(nsub+1) */, hipStream_t s);
 void gz_launch_row_offsets(const int32_t* n_real, int64_t n_rows, uint32_t* off, hipStream_t s);
-void gz_launch_compact(const int32_t* rows, const uint32_t* off, int64_t n_rows, int32_t row_len, void* out, int bits /* 32 | 16 */, hipStream_t s);
-void gz_launch_expand(const void* compact, int bits, const uint32_t* off, int64_t n_rows, int32_t row_len, int32_t pad_id, int32_t* ids,
-                      int32_t* mask, hipStream_t s);
+// first (may be null): receives where each row's entries start (= off[r]): the second array of an exchange block
+void gz_launch_compact(const int32_t* rows, const uint32_t* off, int64_t n_rows, int32_t row_len, void* out, int bits /* 32 | 16 */, uint32_t* first,
+                       hipStream_t s);
+// row r: n_real[r] entries from first[r] on (scanned offsets, or a block's own array: the rows then lie in any order)
+void gz_launch_expand(const void* compact, int bits, const uint32_t* first, const int32_t* n_real, int64_t n_rows, int32_t row_len, int32_t pad_id,
+                      int32_t* ids, int32_t* mask, hipStream_t s);
 void gz_launch_assemble(const GzOptions& O, const GzDeviceTables* T_dev, const GzAsmArgs& A, hipStream_t s);
 void gz_launch_rows_ragged(const GzDeviceTables* T_dev, const GzAsmArgs& A, int pass, int64_t text_bytes, hipStream_t s);
 // small batches, one launch (gz_small.inc): G documents per workgroup, G <= GZ_SMALL_DOCS_PER_WG and every group of G

@@ -27,7 +27,7 @@ SYMBOLS = [
     "gz_vocab_entry", "gz_merge_entry", "gz_encode_batch", "gz_encode_batch_csr", "gz_host_alloc", "gz_host_free", "gz_encode_batch_device", "gz_encode_batch_device_h", "gz_sync",
     "gz_word_token_counts", "gz_bpe_word", "gz_symbol_utf8", "gz_device_alloc", "gz_device_free", "gz_memcpy_h2d", "gz_memcpy_d2h",
     "gz_timing", "gz_timing_history", "gz_decoder_snapshot", "gz_decode_batch", "gz_decode_batch_device", "gz_preprocess_batch",
-    "gz_preprocess_batch_device", "gz_block_create", "gz_block_release", "gz_block_dlpack", "gz_dlpack_capsule_destructor", "gz_exchange_select", "gz_comm_unique_id", "gz_comm_init", "gz_gather_rows", "gz_exchange_timing_history", "gz_compact_rows", "gz_expand_rows", "gz_compact_rows16", "gz_expand_rows16", "gz_compact_block", "gz_expand_block",
+    "gz_preprocess_batch_device", "gz_block_create", "gz_block_release", "gz_block_dlpack", "gz_dlpack_capsule_destructor", "gz_exchange_select", "gz_encode_emit_block", "gz_block_total", "gz_comm_unique_id", "gz_comm_init", "gz_gather_rows", "gz_exchange_timing_history", "gz_compact_rows", "gz_expand_rows", "gz_compact_rows16", "gz_expand_rows16", "gz_compact_block", "gz_expand_block",
     "gz_host_tables_create", "gz_host_tables_destroy", "gz_host_tables_array", "gz_host_tables_vocab_entry",
     "gz_host_tables_merge_entry", "gz_host_tables_symbol", "gz_limit", "gz_debug_set",
 ]
@@ -90,6 +90,8 @@ def load_library():
     L.gz_block_dlpack.argtypes = [vp, i32, vp, i32, i32]; L.gz_block_dlpack.restype = vp
     L.gz_dlpack_capsule_destructor.argtypes = [vp]; L.gz_dlpack_capsule_destructor.restype = None
     L.gz_exchange_select.argtypes = [vp, C.c_int]
+    L.gz_encode_emit_block.argtypes = [vp, vp, i32]
+    L.gz_block_total.argtypes = [vp, i32, P(i64)]
     L.gz_comm_unique_id.argtypes = [vp]
     L.gz_comm_init.argtypes = [vp, vp, C.c_int, C.c_int]
     L.gz_gather_rows.argtypes = [vp, vp, i64, i32, vp, vp, C.c_int]
@@ -458,9 +460,19 @@ class Context:
         fn = self.lib.gz_expand_rows16 if bits == 16 else self.lib.gz_expand_rows
         self._check(fn(self.handle, C.c_void_p(d_compact), C.c_void_p(d_n_real), n_rows, row_len, C.c_void_p(d_ids), C.c_void_p(d_mask)))
 
+    def encode_emit_block(self, d_block, bits: int = 16):
+        """Arms the next (dense) encode call to leave its exchange block in d_block as part of the call (0: disarm)."""
+        self._check(self.lib.gz_encode_emit_block(self.handle, C.c_void_p(d_block) if d_block else None, bits))
+
+    def block_total(self, back: int = 0) -> int:
+        """Waits for the encode call `back` calls ago; the number of entries of the block it emitted."""
+        total = C.c_int64()
+        self._check(self.lib.gz_block_total(self.handle, back, C.byref(total)))
+        return total.value
+
     def compact_block(self, d_rows, d_n_real, n_rows, row_len, d_block, bits: int = 16) -> int:
-        """One rank's message of the exchange step: [int32 n_real[n_rows] | the rows' real entries, `bits` bits each] into
-        d_block; returns the number of entries."""
+        """One rank's message of the exchange step: [int32 n_real[n_rows] | uint32 first[n_rows] | the rows' real entries, `bits`
+        bits each] into d_block; returns the number of entries."""
         total = C.c_int64()
         self._check(self.lib.gz_compact_block(self.handle, C.c_void_p(d_rows), C.c_void_p(d_n_real), n_rows, row_len, bits,
                                               C.c_void_p(d_block), C.byref(total)))

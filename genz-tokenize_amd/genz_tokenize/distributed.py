@@ -69,6 +69,13 @@ def csr_words(n_entries: int, bits: int) -> int:
     return (n_entries * bits // 8 + 3) // 4
 
 
+def block_words(n_rows: int, n_entries: int, bits: int) -> int:
+    """int32 words of one rank's exchange block: [n_real[n_rows] | first[n_rows] | n_entries entries of `bits` bits]."""
+    if n_rows < 0:
+        raise ValueError("n_rows must not be negative")
+    return 2 * n_rows + csr_words(n_entries, bits)
+
+
 class GatherRound:
     """Root-side state of ONE exchange round (local shard j of every rank): where each peer's block starts in the
     receive buffer, how large the buffer must be, and what every peer announced."""

@@ -335,9 +335,18 @@ int  gz_compact_rows16(gz_ctx *ctx, const int32_t *rows_dev, const int32_t *n_re
 int  gz_expand_rows16(gz_ctx *ctx, const uint16_t *compact_dev, const int32_t *n_real_dev, int64_t n_rows, int32_t row_len,
                       int32_t *ids_dev, int32_t *mask_dev);
 /* One rank's whole message of the exchange step as ONE block (one ncclSend per peer and shard):
- *     block_dev = [ int32 n_real[n_rows] | the rows' real entries back to back, `bits` (16 | 32) bits each ]
- * gz_compact_block writes it (total_host receives the number of entries; the block is n_rows + ceil(total * bits / 32)
- * int32 words long), gz_expand_block is the inverse on the receiving side. */
+ *     block_dev = [ int32 n_real[n_rows] | uint32 first[n_rows] | the rows' real entries, `bits` (16 | 32) bits each ]
+ * row r's entries are the n_real[r] ones from entry first[r] on (round 4: no `first` -- the receiver scanned n_real again).
+ * gz_compact_block writes it from dense rows (total_host receives the number of entries; the block is 2 n_rows + ceil(total * bits /
+ * 32) int32 words long), gz_expand_block is the inverse on the receiving side.
+ * gz_encode_emit_block arms the NEXT encode call (a dense one: GZ_E_INVALID from that call otherwise) to leave its block in block_dev
+ * (2 n_docs + ceil(n_docs * max_len * bits / 32) words at most) as part of the call itself: the scan of the row lengths and the
+ * compact kernel run right behind the call's kernels on the call's own stream (beside the NEXT call's kernels, on the exchange
+ * stream, the same work costs those kernels more than it takes here), and nothing of it waits for the host.  gz_block_total(back)
+ * waits for the encode call `back` (0..2) calls ago and returns its block's number of entries (GZ_E_INVALID when that call emitted
+ * none).  block_dev == NULL disarms. */
+int  gz_encode_emit_block(gz_ctx *ctx, int32_t *block_dev, int32_t bits);
+int  gz_block_total(gz_ctx *ctx, int32_t back, int64_t *total_host);
 int  gz_compact_block(gz_ctx *ctx, const int32_t *rows_dev, const int32_t *n_real_dev, int64_t n_rows, int32_t row_len,
                       int32_t bits, int32_t *block_dev, int64_t *total_host);
 int  gz_expand_block(gz_ctx *ctx, const int32_t *block_dev, int32_t bits, int64_t n_rows, int32_t row_len,

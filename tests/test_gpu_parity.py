@@ -1053,7 +1053,7 @@ def test_compact_block_round_trip(tok):
     d_ids, d_nr = ctx.alloc(ids.nbytes), ctx.alloc(4 * n)
     ctx.h2d(d_ids, ids); ctx.h2d(d_nr, nr.astype(np.int32))
     for bits in (16, 32):
-        d_blk = ctx.alloc(4 * (n + n * L)); d_i2, d_m2 = ctx.alloc(ids.nbytes), ctx.alloc(ids.nbytes)
+        d_blk = ctx.alloc(4 * (2 * n + n * L)); d_i2, d_m2 = ctx.alloc(ids.nbytes), ctx.alloc(ids.nbytes)
         total = ctx.compact_block(d_ids, d_nr, n, L, d_blk, bits=bits)
         assert total == int(nr.sum())
         head = np.empty(n, dtype=np.int32); ctx.sync(); ctx.d2h(head, d_blk)
@@ -1064,6 +1064,59 @@ def test_compact_block_round_trip(tok):
         for q in (d_blk, d_i2, d_m2):
             ctx.free(q)
     ctx.free(d_ids); ctx.free(d_nr)
+
+
+@pytest.mark.parametrize("case", ["rows1", "rows1_long", "pairs", "small", "odd_len"])
+def test_encode_emits_its_exchange_block(tok, sampler, case):
+    """gz_encode_emit_block: the encode call leaves its exchange block [n_real | first | entries] itself (the scan of the row lengths and
+    the compact kernel behind its own kernels, on its own stream) -- single texts with max_len 64 (the scan over many workgroups) and
+    256, rows cut at max_len among them, pairs, a batch the one-launch kernel takes, a row length that is no multiple of four.  The
+    block expanded on the "receiving side" must be the call's dense output; gz_block_total must be the sum of n_real; 16- and 32-bit
+    entries; chained calls keep their blocks apart (back = 0, 1, 2)."""
+    from genz_tokenize import _native
+    ctx = tok._ctx
+    n, L = {"rows1": (40000, 64), "rows1_long": (9000, 256), "pairs": (4000, 48), "small": (40, 32), "odd_len": (5000, 30)}[case]
+    ta, oa, _ = corpus.config_corpus(3, n_docs=n, seed=91, sampler=sampler)
+    oa = np.ascontiguousarray(oa, dtype=np.int64); ta = np.ascontiguousarray(ta)
+    pair = case == "pairs"
+    want = tok.encode_packed(ta, oa, ta, oa, max_len=L) if pair else tok.encode_packed(ta, oa, max_len=L)
+    ids, mask, nr = want["input_ids"].reshape(n, L), want["attention_mask"].reshape(n, L), np.asarray(want["n_real"])
+    assert case != "rows1" or (nr == L).any()                   # (some rows are cut)
+    d_t = ctx.alloc(len(ta) + 64); ctx.h2d(d_t, ta)
+    d_o = ctx.alloc(8 * (n + 1)); ctx.h2d(d_o, oa)
+    outs = [[ctx.alloc(4 * n * L) for _ in range(4)] + [ctx.alloc(8 * n + 8), ctx.alloc(4 * n + 4), ctx.alloc(4 * n + 4)] for _ in range(3)]
+    flags = _native.GZ_PADDING | _native.GZ_TRUNCATION
+    for bits in (16, 32):
+        blocks = [ctx.alloc(4 * (2 * n + n * L) + 64) for _ in range(3)]
+        for k in range(3):                                         # three chained calls, each with its own block
+            d_i, d_m, d_tt, d_sq, d_pl, d_r, d_st = outs[k]
+            ctx.encode_emit_block(blocks[k], bits)
+            kw = dict(d_tt=d_tt, d_seq=d_sq, d_pair_len=d_pl, d_status=d_st, h_pair_off=oa) if pair else {}
+            ctx.encode_device(d_t, d_o, d_t if pair else 0, d_o if pair else 0, n, L, flags, n * L, d_i, d_m, d_n_real=d_r, h_text_off=oa, **kw)
+        for k in range(3):
+            assert ctx.block_total(2 - k) == int(nr.sum())
+            ctx.exchange_select(2 - k)
+            d_i2, d_m2 = ctx.alloc(4 * n * L), ctx.alloc(4 * n * L)
+            ctx.expand_block(blocks[k], n, L, d_i2, d_m2, bits=bits); ctx.sync()
+            i2 = np.empty((n, L), np.int32); m2 = np.empty((n, L), np.int32); head = np.empty(n, np.int32)
+            ctx.d2h(i2, d_i2); ctx.d2h(m2, d_m2); ctx.d2h(head, blocks[k])
+            assert np.array_equal(head, nr) and np.array_equal(i2, ids) and np.array_equal(m2, mask)
+            ctx.free(d_i2); ctx.free(d_m2)
+        ctx.exchange_select(0)
+        for b in blocks:
+            ctx.free(b)
+    # a call without the arming has no block; a ragged call refuses the arming
+    ctx.encode_device(d_t, d_o, 0, 0, n, L, flags, n * L, outs[0][0], outs[0][1], d_n_real=outs[0][5], h_text_off=oa); ctx.sync()
+    with pytest.raises(_native.GzError):
+        ctx.block_total(0)
+    blk = ctx.alloc(4 * (2 * n + n * L) + 64)
+    ctx.encode_emit_block(blk, 32)
+    with pytest.raises(_native.GzError):
+        ctx.encode_device(d_t, d_o, 0, 0, n, 0, _native.GZ_MAX_LEN_NONE, len(ta) + 2 * n, outs[0][0], outs[0][1], d_row_off=outs[0][4], d_n_real=outs[0][5], h_text_off=oa)
+    ctx.encode_emit_block(0, 32); ctx.sync()
+    ctx.free(blk)
+    for q in [d_t, d_o] + [x for o in outs for x in o]:
+        ctx.free(q)
 
 
 def test_gather_rows_refuses_bad_arguments_before_opening_a_group(tok):
