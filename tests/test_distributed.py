@@ -99,6 +99,8 @@ def test_shard_ownership_and_root_bookkeeping():
         global_shard_id(0, 1, 8, 8)
     assert [csr_words(t, 16) for t in (0, 1, 2, 3, 4, 5)] == [0, 1, 1, 2, 2, 3]
     assert [csr_words(t, 32) for t in (0, 1, 2)] == [0, 1, 2]
+    from genz_tokenize.distributed import block_words
+    assert block_words(5, 7, 16) == 2 * 5 + 4 and block_words(5, 7, 32) == 2 * 5 + 7 and block_words(0, 0, 16) == 0
     rng = np.random.default_rng(3)
     for world in (2, 4, 8):
         for bits in (16, 32):
