@@ -1106,6 +1106,7 @@ int gz_encode_batch_device(gz_ctx* c, const uint8_t* text, const int64_t* text_o
     const int rc = encode_device_locked(c, text, text_off, pair, pair_off, n_docs, max_len, flags, capacity, input_ids,
                                 attention_mask, token_type_ids, sequence_id, row_off, pair_len, n_real, status, nullptr, nullptr);
     c->caller_buffers = false;
+    c->emit_block = nullptr;                                    // (an arming holds for ONE call, whether that call took it or failed)
     return rc;
 }
 
@@ -1125,6 +1126,7 @@ int gz_encode_batch_device_h(gz_ctx* c, const uint8_t* text, const int64_t* text
                                 attention_mask, token_type_ids, sequence_id, row_off, pair_len, n_real, status,
                                 text_off_host, pair_off_host);
     c->caller_buffers = false;
+    c->emit_block = nullptr;                                    // (an arming holds for ONE call, whether that call took it or failed)
     return rc;
 }
 

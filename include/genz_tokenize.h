@@ -344,7 +344,7 @@ int  gz_expand_rows16(gz_ctx *ctx, const uint16_t *compact_dev, const int32_t *n
  * compact kernel run right behind the call's kernels on the call's own stream (beside the NEXT call's kernels, on the exchange
  * stream, the same work costs those kernels more than it takes here), and nothing of it waits for the host.  gz_block_total(back)
  * waits for the encode call `back` (0..2) calls ago and returns its block's number of entries (GZ_E_INVALID when that call emitted
- * none).  block_dev == NULL disarms. */
+ * none).  An arming holds for ONE gz_encode_batch_device[_h] call -- whether that call makes the block or fails; block_dev == NULL disarms. */
 int  gz_encode_emit_block(gz_ctx *ctx, int32_t *block_dev, int32_t bits);
 int  gz_block_total(gz_ctx *ctx, int32_t back, int64_t *total_host);
 int  gz_compact_block(gz_ctx *ctx, const int32_t *rows_dev, const int32_t *n_real_dev, int64_t n_rows, int32_t row_len,

@@ -1113,7 +1113,10 @@ def test_encode_emits_its_exchange_block(tok, sampler, case):
     ctx.encode_emit_block(blk, 32)
     with pytest.raises(_native.GzError):
         ctx.encode_device(d_t, d_o, 0, 0, n, 0, _native.GZ_MAX_LEN_NONE, len(ta) + 2 * n, outs[0][0], outs[0][1], d_row_off=outs[0][4], d_n_real=outs[0][5], h_text_off=oa)
-    ctx.encode_emit_block(0, 32); ctx.sync()
+    ctx.sync()                                                       # (the refused call used the arming up: the next call emits nothing)
+    ctx.encode_device(d_t, d_o, 0, 0, n, L, flags, n * L, outs[0][0], outs[0][1], d_n_real=outs[0][5], h_text_off=oa); ctx.sync()
+    with pytest.raises(_native.GzError):
+        ctx.block_total(0)
     ctx.free(blk)
     for q in [d_t, d_o] + [x for o in outs for x in o]:
         ctx.free(q)
