@@ -860,14 +860,17 @@ void gz_destroy(gz_ctx* c)
 {
     if (!c) return;
     hipSetDevice(c->device);
-    if (c->stream) hipStreamSynchronize(c->stream);
-    if (c->stream2) { hipStreamSynchronize(c->stream2); hipStreamDestroy(c->stream2); }
+    // every stream of the context drained BEFORE any event or stream goes (an event destroyed under a stream that still waits for it,
+    // a stream destroyed under its last copy: nothing here should depend on how the runtime treats those)
+    for (hipStream_t q : {c->stream, c->stream2, c->side, c->xstream, c->s_in, c->s_out}) if (q) hipStreamSynchronize(q);
+    if (c->stream2) hipStreamDestroy(c->stream2);
     if (c->ev_fork) hipEventDestroy(c->ev_fork);
     if (c->ev_join) hipEventDestroy(c->ev_join);
     for (auto& e : c->ev_tok) if (e) hipEventDestroy(e);
+    for (auto& e : c->ev_blk) if (e) hipEventDestroy(e);
     if (c->ev_x) hipEventDestroy(c->ev_x);
     if (c->xstream) hipStreamDestroy(c->xstream);
-    if (c->side) { hipStreamSynchronize(c->side); hipStreamDestroy(c->side); }
+    if (c->side) hipStreamDestroy(c->side);
     for (auto& a : c->ev_sf0) for (auto& e : a) if (e) hipEventDestroy(e);
     for (auto& a : c->ev_sb) for (auto& e : a) if (e) hipEventDestroy(e);
     for (auto& a : c->ev_sf) for (auto& e : a) if (e) hipEventDestroy(e);
