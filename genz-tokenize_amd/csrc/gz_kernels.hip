@@ -4,8 +4,11 @@
 // wave-cooperative long-word merge) and the small kernels around the pipeline; the pipeline itself -- classify ->
 // scan -> words -> misses -> assemble -- is in gz_pipeline.inc (included below, same translation unit).
 //
-//   gz_rowlen_kernel / gz_scan_kernel / gz_finalize_kernel   ragged layouts only (padding=False, truncation=False,
-//                        max_len None or < 1): row lengths, exclusive scan, copy + pad/cut (tokenize.py:141-146).
+//   gz_rowlen_kernel / gz_scan[64]_kernel   ragged layouts only (padding=False, truncation=False, max_len None or < 1): row lengths,
+//                        their exclusive scan = the rows' places;
+//   gz_finalize_kernel   ... and the copy out of the raw area + pad/cut (tokenize.py:141-146) for pairs and the padded ragged shapes
+//                        (rows without padding of single texts are written straight to their places: gz_rowsr_kernel, gz_pipeline.inc).
+//   gz_scan32x_*_kernel  the 32-bit row offsets of an exchange block / of the CSR host path, over many workgroups.
 //   gz_pair_kernel       sequence_id / token_type_ids of sentence pairs (tokenize.py:154-182, :252-258).
 //   gz_bpe_word_kernel   Tokenize.bpe(token) for one word (symbols out).
 //
