@@ -378,7 +378,15 @@ def main():
     # rank q); the bookkeeping -- block sizes and offsets -- is genz_tokenize.distributed.GatherRound.  The receive buffers
     # are sized ONCE, here, for the worst case (every row of every peer full): nothing is allocated, freed or synchronised
     # for them inside the timed region.
-    rounds = [{"recv": 0, "plan": GatherRound(world, xbits)} for _ in range(m)]
+    # (the rows of every rank's shard of every round: shards of this job are equally large, but the bookkeeping does not rely on it)
+    if dist is not None and world > 1:
+        mine = torch.tensor([sh["n"] for sh in shards], dtype=torch.int64)
+        every = torch.zeros(world * m, dtype=torch.int64)
+        dist.all_gather_into_tensor(every, mine)
+        rows_of = every.view(world, m).tolist()
+    else:
+        rows_of = [[sh["n"] for sh in shards]]
+    rounds = [{"recv": 0, "plan": GatherRound(world, xbits, [rows_of[q][j] for q in range(world)])} for j in range(m)]
     if gather:
         if not gloo:
             uid = [ctx.comm_unique_id() if rank == 0 else None]
@@ -386,7 +394,7 @@ def main():
             ctx.comm_init(uid[0], rank, world)
         if rank == 0:
             for r in rounds:
-                r["plan"].capacity = world * block_words(n, n * L, xbits)
+                r["plan"].capacity = r["plan"].worst_case_words(L)
                 r["recv"] = ctx.alloc(4 * r["plan"].capacity)
 
     def gloo_gatherv(d_src, my_words, d_dst, words):
@@ -434,16 +442,16 @@ def main():
         size_in[0] = int(total)
         dist.all_gather_into_tensor(size_out, size_in)
         t_c = time.perf_counter()
-        plan.announce(size_out.tolist())                          # entries per rank -> words per rank (n_real header not included)
-        words = [2 * n + w for w in plan.words]                  # a block = n row lengths + n first entries + the entries
-        if rank == 0 and sum(words) > plan.capacity:
+        need = plan.announce(size_out.tolist())                   # entries per rank -> int32 words of every rank's whole block
+        words = plan.words
+        if rank == 0 and need != plan.capacity:
             sys.exit("bench: receive buffer too small (cannot happen: it holds the worst case)")
         if gloo:
             gloo_gatherv(st["block"], words[rank], r["recv"], words)
         else:
             ctx.gather_rows(st["block"], words[rank], 1, r["recv"] if rank == 0 else 0, words, 0)
         t_d = time.perf_counter()
-        r["words"] = words
+        r["words"] = list(words)
         if x_on[0]:
             xt["compact_sync"].append(t_b - t_a); xt["size_exchange"].append(t_c - t_b); xt["gather_host"].append(t_d - t_c)
             xt["block_bytes"].append(4 * words[rank])
@@ -546,7 +554,7 @@ def main():
             plan = r["plan"]
             for q in range(world):
                 gid = global_shard_id(q, j, world, N_SHARDS)
-                ctx.expand_block(r["recv"] + 4 * sum(r["words"][:q]), n, L, d_ci, d_cm, bits=xbits)
+                ctx.expand_block(r["recv"] + 4 * plan.word_offset(q), plan.rows[q], L, d_ci, d_cm, bits=xbits, total=plan.totals[q])
                 ctx.sync()
                 blk = np.empty((n, L), dtype=np.int32); ctx.d2h(blk, d_ci)
                 mblk = np.empty((n, L), dtype=np.int32); ctx.d2h(mblk, d_cm)

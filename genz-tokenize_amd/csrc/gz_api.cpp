@@ -163,6 +163,11 @@ struct gz_ctx {
     DBuf w_csr_ids[2], w_csr_mask[2], w_csr_comp, w_csr_nreal, w_csr_off32;
     uint32_t* h_tot = nullptr;           // pinned: compact size of every sub-batch
     uint8_t* h_stage = nullptr; size_t h_stage_cap = 0;      // pinned staging of small host calls (one copy in, one copy out)
+    // pinned buffers of the host paths (gz_hostpath.h): the caller's memory is never handed to a HIP copy
+    uint8_t* h_xfer[2] = {nullptr, nullptr}; size_t h_xfer_cap[2] = {0, 0};          // copy_in / copy_out: two pieces in flight
+    hipEvent_t ev_xfer[2] = {nullptr, nullptr}; bool xfer_busy[2] = {false, false};
+    uint8_t* h_tin[2] = {nullptr, nullptr}; size_t h_tin_cap[2] = {0, 0};            // text of the sub-batches of a large host call, on its way in
+    uint8_t* h_cout[3] = {nullptr, nullptr, nullptr}; size_t h_cout_cap[3] = {0, 0, 0};    // ... their compact rows, on their way out
     DBuf w_stage;
     int cache_status = 0;                // of the last gz_load_tables: 0 no cache, 1 hit, 2 miss (written), 3 a file was refused (rebuilt, rewritten), 4 rebuilt but not written
     bool building_words = false;         // the whole-word table is being built: ignore diagnostics
@@ -178,8 +183,25 @@ int fail(gz_ctx* c, int code, const char* fmt, ...)
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (c) c->err = buf; else g_create_err = buf;
+    try { if (c) c->err = buf; else g_create_err = buf; } catch (...) { /* no memory even for the message: the code still says what happened */ }
     return code;
+}
+
+// No C++ exception crosses the C ABI: every extern "C" function of this file is a function-try-block that ends in one of
+// these handlers (locks and buffers owned by the frame are released by the unwinding before the handler runs).
+#define GZ_CATCH(c)                                                                                               \
+    catch (const std::bad_alloc&) { return fail((c), GZ_E_NOMEM, "%s: out of host memory", __func__); }            \
+    catch (const std::exception& e_) { return fail((c), GZ_E_HIP, "%s: unexpected C++ exception: %s", __func__, e_.what()); } \
+    catch (...) { return fail((c), GZ_E_HIP, "%s: unexpected C++ exception", __func__); }
+#define GZ_CATCH_VOID catch (...) { }
+#define GZ_CATCH_NULL catch (...) { return nullptr; }
+
+// Test hook (switch `inject_bad_alloc` = k > 0): the k-th allocation site of the entry points reached from now on throws
+// std::bad_alloc, as the allocation behind it would on a host that is out of memory.  Sites: wherever an extern "C" body grows
+// a std::vector / std::string.  0 (the default) costs one load and a branch per site.
+void alloc_site(gz_ctx* c)
+{
+    if (c->opt.inject_bad_alloc > 0 && --c->opt.inject_bad_alloc == 0) throw std::bad_alloc();
 }
 
 #define HIPCHK(c, call)                                                                              \
@@ -188,12 +210,86 @@ int fail(gz_ctx* c, int code, const char* fmt, ...)
         if (e_ != hipSuccess) return fail((c), GZ_E_HIP, "%s: %s", #call, hipGetErrorString(e_));    \
     } while (0)
 
+#ifdef GZ_DIAG
+// ---- guard-granule allocator (diagnostic build, switch diag_guard) ---------------------------------------------------------
+// The index assertions of this build cover indices that COME OUT OF MEMORY.  An index a kernel COMPUTES -- a tile's look-ahead
+// load near the end of its buffer, the 16 bytes at a word's start -- overruns silently as long as the bytes behind the buffer are
+// mapped, which with hipMalloc they almost always are (it carves buffers out of large blocks): such an overrun faults only on the
+// day the allocator's layout puts an unmapped page there.  Here every workspace / table buffer is its OWN virtual-memory mapping
+// with an unmapped granule on both sides and NO slack: diag_guard = 1 puts the buffer's END on the last byte of its mapping
+// (16-byte aligned start), = 2 its START on the first byte.  One byte too far faults on the spot, every time, and the runtime's
+// fault message (AMD_LOG_LEVEL=1 names the kernel) replaces a coin toss.
+struct GuardMap { void* base; size_t reserved; void* map_at; size_t mapped; hipMemGenericAllocationHandle_t h; };
+std::mutex g_guard_mu;
+std::unordered_map<void*, GuardMap> g_guard;                 // user pointer -> its mapping
+
+int guard_alloc(gz_ctx* c, void** out, size_t bytes, int mode)
+{
+    hipMemAllocationProp prop{};
+    prop.type = hipMemAllocationTypePinned;
+    prop.location.type = hipMemLocationTypeDevice;
+    prop.location.id = c->device;
+    size_t gran = 0;
+    hipError_t e = hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum);
+    if (e != hipSuccess || gran == 0) return fail(c, GZ_E_HIP, "diag_guard: hipMemGetAllocationGranularity: %s", hipGetErrorString(e));
+    const size_t want = (bytes + 15) & ~(size_t)15;
+    GuardMap g{};
+    g.mapped = (want + gran - 1) / gran * gran;
+    g.reserved = g.mapped + 2 * gran;
+    if ((e = hipMemAddressReserve(&g.base, g.reserved, gran, nullptr, 0)) != hipSuccess) return fail(c, GZ_E_NOMEM, "diag_guard: hipMemAddressReserve(%zu): %s", g.reserved, hipGetErrorString(e));
+    g.map_at = (uint8_t*)g.base + gran;
+    if ((e = hipMemCreate(&g.h, g.mapped, &prop, 0)) != hipSuccess) { hipMemAddressFree(g.base, g.reserved); return fail(c, GZ_E_NOMEM, "diag_guard: hipMemCreate(%zu): %s", g.mapped, hipGetErrorString(e)); }
+    if ((e = hipMemMap(g.map_at, g.mapped, 0, g.h, 0)) != hipSuccess) { hipMemRelease(g.h); hipMemAddressFree(g.base, g.reserved); return fail(c, GZ_E_HIP, "diag_guard: hipMemMap: %s", hipGetErrorString(e)); }
+    hipMemAccessDesc acc{};
+    acc.location = prop.location;
+    acc.flags = hipMemAccessFlagsProtReadWrite;
+    if ((e = hipMemSetAccess(g.map_at, g.mapped, &acc, 1)) != hipSuccess) {
+        hipMemUnmap(g.map_at, g.mapped); hipMemRelease(g.h); hipMemAddressFree(g.base, g.reserved);
+        return fail(c, GZ_E_HIP, "diag_guard: hipMemSetAccess: %s", hipGetErrorString(e));
+    }
+    void* user = mode == 1 ? (void*)((uint8_t*)g.map_at + g.mapped - want) : g.map_at;
+    { std::lock_guard<std::mutex> lk(g_guard_mu); g_guard[user] = g; }
+    *out = user;
+    return GZ_OK;
+}
+bool guard_free(void* user)
+{
+    GuardMap g;
+    {
+        std::lock_guard<std::mutex> lk(g_guard_mu);
+        auto it = g_guard.find(user);
+        if (it == g_guard.end()) return false;
+        g = it->second;
+        g_guard.erase(it);
+    }
+    hipDeviceSynchronize();
+    hipMemUnmap(g.map_at, g.mapped);
+    hipMemRelease(g.h);
+    hipMemAddressFree(g.base, g.reserved);
+    return true;
+}
+void dev_free(void* p) { if (p && !guard_free(p)) hipFree(p); }
+#else
+void dev_free(void* p) { if (p) hipFree(p); }
+#endif
+
 // zero_new: a fresh allocation is cleared before anything uses it (the chained-scan words are validated by a per-context
 // call number only: memory another context freed could otherwise carry words that look current)
 int ensure(gz_ctx* c, DBuf& b, size_t bytes, bool zero_new = false)
 {
     if (bytes <= b.cap && b.p) return GZ_OK;
-    if (b.p) { hipFree(b.p); b.p = nullptr; b.cap = 0; }
+    if (b.p) { dev_free(b.p); b.p = nullptr; b.cap = 0; }
+#ifdef GZ_DIAG
+    if (c->opt.diag_guard) {
+        // exactly what was asked for (rounded up to 16 bytes): no slack, an unmapped granule on both sides
+        const size_t want = ((bytes ? bytes : 16) + 15) & ~(size_t)15;
+        int rc = guard_alloc(c, &b.p, want, c->opt.diag_guard);
+        if (rc) { b.p = nullptr; return rc; }
+        b.cap = want;
+        if (zero_new && hipMemset(b.p, 0, want) != hipSuccess) return fail(c, GZ_E_HIP, "hipMemset of a new workspace buffer failed");
+        return GZ_OK;
+    }
+#endif
     size_t want = bytes + 256;                      // slack: tile loads may touch up to 15 bytes past the text
     want = (want + 4095) & ~(size_t)4095;
     hipError_t e = hipMalloc(&b.p, want);
@@ -203,7 +299,11 @@ int ensure(gz_ctx* c, DBuf& b, size_t bytes, bool zero_new = false)
     return GZ_OK;
 }
 
-void release(DBuf& b) { if (b.p) hipFree(b.p); b.p = nullptr; b.cap = 0; }
+void release(DBuf& b) { if (b.p) dev_free(b.p); b.p = nullptr; b.cap = 0; }
+
+}  // namespace
+#include "gz_hostpath.h"
+namespace {
 
 template <class V>
 int upload(gz_ctx* c, DBuf& b, const V& v)
@@ -211,8 +311,7 @@ int upload(gz_ctx* c, DBuf& b, const V& v)
     size_t bytes = v.size() * sizeof(v[0]);
     int rc = ensure(c, b, bytes ? bytes : 16);
     if (rc) return rc;
-    if (bytes) HIPCHK(c, hipMemcpyAsync(b.p, v.data(), bytes, hipMemcpyHostToDevice, c->stream));
-    return GZ_OK;
+    return copy_in(c, b.p, v.data(), bytes, c->stream);
 }
 
 bool is_dense(const GzShape& S) { return S.pad_mode && S.truncation && S.max_len >= 1; }
@@ -338,7 +437,16 @@ int sync_locked(gz_ctx* c)
         HIPCHK(c, hipMemcpyAsync(c->h_flags, c->w_flags.p, 8, hipMemcpyDeviceToHost, c->stream));
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (c->x_used) HIPCHK(c, hipStreamSynchronize(c->xstream));
+    if (c->x_used) {
+        HIPCHK(c, hipStreamSynchronize(c->xstream));
+        int32_t* const bad = reinterpret_cast<int32_t*>(reinterpret_cast<uint8_t*>(c->h_pick) + 384);
+        if (*bad) {
+            *bad = 0;
+            HIPCHK(c, hipMemset((int32_t*)c->w_flags.p + 12, 0, 4));
+            c->pend.active = false;
+            return fail(c, GZ_E_INVALID, "an exchange block did not fit what was announced for it (a row longer than a row, or entries beyond the block's total): truncated, or written in another layout");
+        }
+    }
 #ifdef GZ_DIAG
     {
         // diagnostic build: an index the kernels took out of memory did not fit the array it was meant for (the access was skipped)
@@ -461,7 +569,8 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
                          const int64_t* pair_off, int64_t n_docs, int32_t max_len, uint32_t flags, int64_t capacity,
                          int32_t* input_ids, int32_t* attention_mask, int32_t* token_type_ids, int32_t* sequence_id,
                          int64_t* row_off, int32_t* pair_len, int32_t* n_real, int32_t* status,
-                         const int64_t* h_text_off /* host copy of the offsets, or nullptr */, const int64_t* h_pair_off)
+                         const int64_t* h_text_off /* host copy of the offsets, or nullptr */, const int64_t* h_pair_off,
+                         int32_t* emit_block = nullptr /* gz_encode_emit_block's arming, taken by the device entry points only */, int32_t emit_bits = 0)
 {
     if (!c->have_tables) return fail(c, GZ_E_NOTABLES, "gz_load_tables has not been called");
     if (n_docs < 0 || !text_off || (n_docs > 0 && !text)) return fail(c, GZ_E_INVALID, "bad text arguments");
@@ -582,6 +691,7 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
     p.ragged_direct = direct_ok && !p.small;
     p.text_bytes = text_bytes;
     if (p.ragged_direct) n_raw = n_real;                       // (the count pass writes the row lengths where the caller wants them)
+    alloc_site(c);
     p.subs.resize((size_t)nsub);
     for (int k = 0; k < nsub; ++k) {
         const int64_t lo = (int64_t)k * n_docs / nsub, hi = (int64_t)(k + 1) * n_docs / nsub;
@@ -600,12 +710,11 @@ int encode_device_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off
             if (rc2) return rc2;
         }
     }
-    if (c->emit_block) {
+    if (emit_block) {
         // the call's exchange block: [n_real[n] | first[n] | entries]
         if (!dense) return fail(c, GZ_E_INVALID, "gz_encode_emit_block needs a dense call (padding, truncation, max_len >= 1)");
-        p.emit_block = c->emit_block; p.emit_bits = c->emit_bits; p.emit_slot = (int32_t)(c->enc_seq & 3);
+        p.emit_block = emit_block; p.emit_bits = emit_bits; p.emit_slot = (int32_t)(c->enc_seq & 3);
         p.emit_rows = input_ids; p.emit_nreal = n_real; p.emit_n = n_docs; p.emit_len = max_len;
-        c->emit_block = nullptr;
         if (!c->ev_blk[p.emit_slot]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_blk[p.emit_slot], hipEventDisableTiming));
         if ((rc = ensure(c, c->w_rowoff32, (size_t)(n_docs + 2) * 4))) return rc;       // (the fallback's scan)
     }
@@ -793,7 +902,8 @@ static int install_word_tables(gz_ctx* c, const WordImages& W)
     D.word0_ovf = W.ph.n_overflow;
     D.word_hot = (const GzWordHot*)c->t_word_hot.p;
     if (!W.tab2.empty()) { D.words2 = (const GzWordSlot2*)c->t_words2.p; D.word2_mask = (uint32_t)W.tab2.size() - 1; }
-    HIPCHK(c, hipMemcpy(c->t_struct.p, &c->dev, sizeof(GzDeviceTables), hipMemcpyHostToDevice));
+    { int rcs = copy_in(c, c->t_struct.p, &c->dev, sizeof(GzDeviceTables), c->stream); if (rcs) return rcs; }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     c->n_words = W.n_words;
     return GZ_OK;
 }
@@ -805,7 +915,7 @@ extern "C" {
 int gz_version(void) { return GZ_VERSION; }
 
 int gz_create(int device_id, gz_ctx** out)
-{
+try {
     if (!out) return GZ_E_INVALID;
     *out = nullptr;
     static const bool load_timing = getenv("GZ_LOAD_TIMING") != nullptr;
@@ -848,16 +958,17 @@ int gz_create(int device_id, gz_ctx** out)
     for (auto& e : c->ev_tok) hipEventCreateWithFlags(&e, hipEventDisableTiming);
     hipEventCreateWithFlags(&c->ev_x, hipEventDisableTiming);
     phase("streams and events");
-    hipHostMalloc((void**)&c->h_pick, 256, hipHostMallocDefault);
+    if (hipHostMalloc((void**)&c->h_pick, 512, hipHostMallocDefault) != hipSuccess) { gz_destroy(c); return fail(nullptr, GZ_E_NOMEM, "pinned memory creation failed"); }
+    std::memset(c->h_pick, 0, 512);
     phase("pinned pick buffer");
-    if (ensure(c, c->w_flags, 64) != GZ_OK) { g_create_err = c->err; gz_destroy(c); return GZ_E_NOMEM; }
+    if (ensure(c, c->w_flags, 64, /* zeroed: word 12 is only ever raised */ true) != GZ_OK) { g_create_err = c->err; gz_destroy(c); return GZ_E_NOMEM; }
     phase("device flags");
     *out = c;
     return GZ_OK;
-}
+} GZ_CATCH(nullptr)
 
 void gz_destroy(gz_ctx* c)
-{
+try {
     if (!c) return;
     hipSetDevice(c->device);
     // every stream of the context drained BEFORE any event or stream goes (an event destroyed under a stream that still waits for it,
@@ -881,6 +992,10 @@ void gz_destroy(gz_ctx* c)
     for (auto& e : c->ev_done) if (e) hipEventDestroy(e);
     if (c->h_tot) hipHostFree(c->h_tot);
     if (c->h_stage) hipHostFree(c->h_stage);
+    for (auto& h : c->h_xfer) if (h) hipHostFree(h);
+    for (auto& h : c->h_tin) if (h) hipHostFree(h);
+    for (auto& h : c->h_cout) if (h) hipHostFree(h);
+    for (auto& e : c->ev_xfer) if (e) hipEventDestroy(e);
     release(c->w_stage);
     for (DBuf* b : {&c->w_csr_ids[0], &c->w_csr_ids[1], &c->w_csr_mask[0], &c->w_csr_mask[1], &c->w_csr_comp, &c->w_csr_nreal, &c->w_csr_off32}) release(*b);
     if (c->h_pick) hipHostFree(c->h_pick);
@@ -902,13 +1017,13 @@ void gz_destroy(gz_ctx* c)
     if (c->h_flags) hipHostFree(c->h_flags);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
-}
+} GZ_CATCH_VOID
 
 const char* gz_last_error(gz_ctx* c) { return c ? c->err.c_str() : g_create_err.c_str(); }
 
 int gz_load_tables(gz_ctx* c, const uint8_t* vocab, size_t vocab_len, const uint8_t* bpe, size_t bpe_len,
                    const char* const specials[5])
-{
+try {
     if (!c || (!vocab && vocab_len) || (!bpe && bpe_len) || !specials) return c ? fail(c, GZ_E_INVALID, "bad arguments") : GZ_E_INVALID;
     for (int i = 0; i < 5; ++i) if (!specials[i]) return fail(c, GZ_E_INVALID, "special token %d is NULL", i);
     std::lock_guard<std::mutex> lk(c->mu);
@@ -973,7 +1088,8 @@ int gz_load_tables(gz_ctx* c, const uint8_t* vocab, size_t vocab_len, const uint
     D.word_hot = nullptr;
     if (c->host.enc_words.size() >= (1u << 26)) return fail(c, GZ_E_LIMIT, "vocab has 2^26 or more entries");
     if ((rc = ensure(c, c->t_struct, sizeof(GzDeviceTables)))) return rc;
-    HIPCHK(c, hipMemcpy(c->t_struct.p, &c->dev, sizeof(GzDeviceTables), hipMemcpyHostToDevice));
+    { int rcs = copy_in(c, c->t_struct.p, &c->dev, sizeof(GzDeviceTables), c->stream); if (rcs) return rcs; }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     c->have_tables = true;
     phase("upload of the pair / symbol tables");
     if (!hit) {
@@ -991,27 +1107,27 @@ int gz_load_tables(gz_ctx* c, const uint8_t* vocab, size_t vocab_len, const uint
         phase("cache write");
     }
     return GZ_OK;
-}
+} GZ_CATCH(c)
 
 int gz_debug_set(gz_ctx* c, const char* key, int64_t value)
-{
+try {
     // c == NULL: the process-wide defaults (contexts created from now on, and the table builder); else this context
     int rc;
     if (c) { std::lock_guard<std::mutex> lk(c->mu); rc = gz_option_set(c->opt, key, value); }
     else rc = gz_option_set(gz_default_options(), key, value);
     if (rc) return fail(c, GZ_E_INVALID, "gz_debug_set: unknown key or value out of range: %s = %lld", key ? key : "(null)", (long long)value);
     return GZ_OK;
-}
+} GZ_CATCH(c)
 
 int gz_table_cache_status(gz_ctx* c)
-{
+try {
     return c ? c->cache_status : GZ_E_INVALID;
-}
+} GZ_CATCH(c)
 
 // SHA-256 over every device-resident table image and the descriptor's scalar fields: two contexts whose tables were built
 // from the same files -- one by the builder, one from the cache -- must give the same digest.
 int gz_table_digest(gz_ctx* c, uint8_t out[32])
-{
+try {
     if (!c || !out) return GZ_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mu);
     if (!c->have_tables) return fail(c, GZ_E_NOTABLES, "gz_load_tables has not been called");
@@ -1023,8 +1139,9 @@ int gz_table_digest(gz_ctx* c, uint8_t out[32])
         const uint64_t n = bytes;
         sha.update(&n, 8);
         if (!bytes) return GZ_OK;
+        alloc_site(c);
         buf.resize(bytes);
-        HIPCHK(c, hipMemcpy(buf.data(), dptr, bytes, hipMemcpyDeviceToHost));
+        { int rcs = copy_out(c, buf.data(), dptr, bytes, c->stream); if (rcs) return rcs; }
         sha.update(buf.data(), bytes);
         return GZ_OK;
     };
@@ -1054,10 +1171,10 @@ int gz_table_digest(gz_ctx* c, uint8_t out[32])
     for (const std::string& w : H.symbols) { const uint32_t l = (uint32_t)w.size(); sha.update(&l, 4); sha.update(w.data(), l); }
     sha.final(out);
     return GZ_OK;
-}
+} GZ_CATCH(c)
 
 int gz_table_info(gz_ctx* c, int32_t* vocab_size, int32_t special_ids[5], int32_t* n_ranks, int32_t* n_symbols)
-{
+try {
     if (!c) return GZ_E_INVALID;
     if (!c->have_tables) return fail(c, GZ_E_NOTABLES, "gz_load_tables has not been called");
     if (vocab_size) *vocab_size = (int32_t)c->host.enc_words.size();
@@ -1065,20 +1182,20 @@ int gz_table_info(gz_ctx* c, int32_t* vocab_size, int32_t special_ids[5], int32_
     if (n_ranks) *n_ranks = (int32_t)c->host.rank_keys.size();
     if (n_symbols) *n_symbols = (int32_t)c->host.symbols.size();
     return GZ_OK;
-}
+} GZ_CATCH(c)
 
 int gz_vocab_entry(gz_ctx* c, int64_t i, const uint8_t** utf8, int32_t* len, int32_t* id)
-{
+try {
     if (!c || !c->have_tables) return c ? fail(c, GZ_E_NOTABLES, "no tables") : GZ_E_INVALID;
     if (i < 0 || i >= (int64_t)c->host.enc_words.size()) return GZ_E_INVALID;
     if (utf8) *utf8 = (const uint8_t*)c->host.enc_words[i].data();
     if (len) *len = (int32_t)c->host.enc_words[i].size();
     if (id) *id = c->host.enc_ids[i];
     return GZ_OK;
-}
+} GZ_CATCH(c)
 
 int gz_merge_entry(gz_ctx* c, int64_t i, const uint8_t** utf8, int32_t* len, int32_t* n_fields, int32_t* rank)
-{
+try {
     if (!c || !c->have_tables) return c ? fail(c, GZ_E_NOTABLES, "no tables") : GZ_E_INVALID;
     if (i < 0 || i >= (int64_t)c->host.rank_keys.size()) return GZ_E_INVALID;
     if (utf8) *utf8 = (const uint8_t*)c->host.rank_keys[i].data();
@@ -1086,60 +1203,261 @@ int gz_merge_entry(gz_ctx* c, int64_t i, const uint8_t** utf8, int32_t* len, int
     if (n_fields) *n_fields = c->host.rank_nfields[i];
     if (rank) *rank = c->host.rank_vals[i];
     return GZ_OK;
-}
+} GZ_CATCH(c)
 
 int gz_symbol_utf8(gz_ctx* c, int32_t symbol, const uint8_t** utf8, int32_t* len)
-{
+try {
     if (!c || !c->have_tables) return c ? fail(c, GZ_E_NOTABLES, "no tables") : GZ_E_INVALID;
     if (symbol < 0 || symbol >= (int32_t)c->host.symbols.size()) return GZ_E_INVALID;
     if (utf8) *utf8 = (const uint8_t*)c->host.symbols[symbol].data();
     if (len) *len = (int32_t)c->host.symbols[symbol].size();
     return GZ_OK;
-}
+} GZ_CATCH(c)
 
 int gz_encode_batch_device(gz_ctx* c, const uint8_t* text, const int64_t* text_off, const uint8_t* pair,
                            const int64_t* pair_off, int64_t n_docs, int32_t max_len, uint32_t flags, int64_t capacity,
                            int32_t* input_ids, int32_t* attention_mask, int32_t* token_type_ids, int32_t* sequence_id,
                            int64_t* row_off, int32_t* pair_len, int32_t* n_real, int32_t* status)
-{
+try {
     if (!c) return GZ_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
-    c->caller_buffers = true;
-    const int rc = encode_device_locked(c, text, text_off, pair, pair_off, n_docs, max_len, flags, capacity, input_ids,
-                                attention_mask, token_type_ids, sequence_id, row_off, pair_len, n_real, status, nullptr, nullptr);
-    c->caller_buffers = false;
-    c->emit_block = nullptr;                                    // (an arming holds for ONE call, whether that call took it or failed)
-    return rc;
-}
+    // (an arming of gz_encode_emit_block holds for ONE call of the DEVICE entry points, whether that call takes it or fails; host
+    //  calls and gz_load_tables -- which encode through the same function -- never see it)
+    int32_t* const blk = c->emit_block; c->emit_block = nullptr;
+    struct Flag { bool& f; explicit Flag(bool& x) : f(x) { f = true; } ~Flag() { f = false; } } caller(c->caller_buffers);
+    return encode_device_locked(c, text, text_off, pair, pair_off, n_docs, max_len, flags, capacity, input_ids,
+                                attention_mask, token_type_ids, sequence_id, row_off, pair_len, n_real, status, nullptr, nullptr, blk, c->emit_bits);
+} GZ_CATCH(c)
 
 int gz_encode_batch_device_h(gz_ctx* c, const uint8_t* text, const int64_t* text_off, const uint8_t* pair,
                              const int64_t* pair_off, int64_t n_docs, int32_t max_len, uint32_t flags, int64_t capacity,
                              int32_t* input_ids, int32_t* attention_mask, int32_t* token_type_ids, int32_t* sequence_id,
                              int64_t* row_off, int32_t* pair_len, int32_t* n_real, int32_t* status,
                              const int64_t* text_off_host, const int64_t* pair_off_host)
-{
+try {
     if (!c) return GZ_E_INVALID;
     if (!text_off_host || ((pair_off != nullptr) != (pair_off_host != nullptr)))
         return fail(c, GZ_E_INVALID, "host copies of the offsets are required for every text");
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
-    c->caller_buffers = true;
-    const int rc = encode_device_locked(c, text, text_off, pair, pair_off, n_docs, max_len, flags, capacity, input_ids,
+    int32_t* const blk = c->emit_block; c->emit_block = nullptr;        // (as above)
+    struct Flag { bool& f; explicit Flag(bool& x) : f(x) { f = true; } ~Flag() { f = false; } } caller(c->caller_buffers);
+    return encode_device_locked(c, text, text_off, pair, pair_off, n_docs, max_len, flags, capacity, input_ids,
                                 attention_mask, token_type_ids, sequence_id, row_off, pair_len, n_real, status,
-                                text_off_host, pair_off_host);
-    c->caller_buffers = false;
-    c->emit_block = nullptr;                                    // (an arming holds for ONE call, whether that call took it or failed)
-    return rc;
-}
+                                text_off_host, pair_off_host, blk, c->emit_bits);
+} GZ_CATCH(c)
 
 int gz_sync(gz_ctx* c)
-{
+try {
     if (!c) return GZ_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     return sync_locked(c);
+} GZ_CATCH(c)
+
+// ---- large host calls: sub-batches, copies overlapped with the kernels ---------------------------------------------------
+// Host buffers in; out either CSR (gz_encode_batch_csr: the rows' real entries + row lengths) or DENSE (gz_encode_batch with
+// padding + truncation: [n_docs, max_len] ids + mask).  The batch is cut into sub-batches of documents:
+//   caller's thread: text of sub-batch k + 1 into a pinned buffer (worker threads), onto the copy-in stream, while
+//   main stream    : the pipeline of sub-batch k runs (dense rows into one of two device slots), then the rows lose
+//                    their padding (scan of n_real + gz_compact_kernel) into the sub-batch's region of a device buffer,
+//   copy-out stream: the real entries of sub-batch k - 1 travel back into a pinned slot,
+//   worker threads : sub-batch k - 2's entries go to their final place in the caller's array -- or, dense form, are PADDED ON
+//                    THE HOST into the caller's [n_docs, max_len] arrays.
+// What crosses PCIe either way is the text, 8 bytes per document of offsets, and 2 (or 4) bytes per real token + 4 per document:
+// for the dense form 0.1 GB instead of the 2 GB of mostly padding its arrays hold (1 M documents, max_len 256).
+// Buffers that came from gz_host_alloc skip the pinned staging (they are pinned): copies go straight in / out.
+struct CsrOut {
+    void* tokens = nullptr; int64_t capacity = 0;       // CSR form: entries back to back (capacity in entries) ...
+    int32_t* n_real = nullptr;                          // ... and the row lengths (dense form: may be null)
+    int32_t* ids = nullptr; int32_t* mask = nullptr;    // dense form
+};
+
+static int csr_core(gz_ctx* c, const uint8_t* text, const int64_t* text_off, int64_t n_docs, int32_t max_len, uint32_t flags, int bits,
+                    const CsrOut& O, int64_t* total_out)
+{
+    const bool dense_out = O.ids != nullptr;
+    const int64_t tb = text_off[n_docs] - text_off[0];
+    if (c->pend.active) { int rc0 = sync_locked(c); if (rc0) return rc0; }
+    if (c->x_used) HIPCHK(c, hipStreamSynchronize(c->xstream));
+    if (!c->s_in) {
+        HIPCHK(c, hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking));
+        for (auto& e : c->ev_in) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto& e : c->ev_done) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIPCHK(c, hipHostMalloc((void**)&c->h_tot, sizeof(uint32_t) * gz_ctx::CSR_SUBS, hipHostMallocDefault));
+    }
+    // sub-batches of about 32 MB of text (equal document counts), at most CSR_SUBS
+    int nsub = (int)((tb + (32ll << 20) - 1) / (32ll << 20));
+    if (dense_out) {                                            // ... and of at most 256 MB of dense rows (short documents, long rows)
+        const int64_t by_rows = (n_docs * (int64_t)max_len * 8 + (256ll << 20) - 1) / (256ll << 20);
+        if (by_rows > nsub) nsub = (int)std::min<int64_t>(by_rows, gz_ctx::CSR_SUBS);
+    }
+    if (nsub < 1) nsub = 1;
+    if (nsub > gz_ctx::CSR_SUBS) nsub = gz_ctx::CSR_SUBS;
+    if ((int64_t)nsub > n_docs) nsub = (int)n_docs;
+    const size_t esz = bits == 16 ? 2 : 4;
+    auto lo_of = [&](int k) { return (int64_t)k * n_docs / nsub; };
+    int64_t nmax = 0, bmax = 0;
+    for (int k = 0; k < nsub; ++k) {
+        nmax = std::max(nmax, lo_of(k + 1) - lo_of(k));
+        bmax = std::max(bmax, text_off[lo_of(k + 1)] - text_off[lo_of(k)]);
+    }
+    // a document of b bytes has at most min(max_len, b + 2) entries: regions of the device compact buffer start at these bounds
+    alloc_site(c);
+    std::vector<int64_t> bound((size_t)nsub + 1, 0);
+    for (int k = 0; k < nsub; ++k) {
+        const int64_t lo = lo_of(k), hi = lo_of(k + 1);
+        const int64_t by_bytes = (text_off[hi] - text_off[lo]) + 2 * (hi - lo), by_rows = (hi - lo) * (int64_t)max_len;
+        int64_t b = by_bytes < by_rows ? by_bytes : by_rows;
+        b = (b + 7) & ~(int64_t)7;                                          // regions stay 16-byte aligned for either entry size
+        bound[(size_t)k + 1] = bound[(size_t)k] + b;
+    }
+    int rc;
+    if ((rc = ensure(c, c->w_text, (size_t)tb + 16)) || (rc = ensure(c, c->w_toff, (size_t)(n_docs + 1) * 8)) ||
+        (rc = ensure(c, c->w_csr_nreal, (size_t)(n_docs + 1) * 4)) || (rc = ensure(c, c->w_csr_off32, (size_t)(nmax + 2) * 4)) ||
+        (rc = ensure(c, c->w_csr_comp, (size_t)bound[(size_t)nsub] * esz + 64)))
+        return rc;
+    for (int q = 0; q < (nsub > 1 ? 2 : 1); ++q)
+        if ((rc = ensure(c, c->w_csr_ids[q], (size_t)nmax * (size_t)max_len * 4 + 64)) || (rc = ensure(c, c->w_csr_mask[q], (size_t)nmax * (size_t)max_len * 4 + 64)))
+            return rc;
+    const GzDeviceTables* T = (const GzDeviceTables*)c->t_struct.p;
+    const uint8_t* d_text = (const uint8_t*)c->w_text.p - text_off[0];
+    const int64_t* d_off = (const int64_t*)c->w_toff.p;
+    const int use_words = use_words_flags(c, flags);
+    hipStream_t s = c->stream;
+    if ((rc = need_side_streams(c, false))) return rc;
+
+    // which of the caller's buffers are pinned (gz_host_alloc): those are copied directly
+    const bool text_direct = tb >= 65536 && is_pinned(text);
+    const bool out_direct = !dense_out && is_pinned(O.n_real) && (O.capacity == 0 || is_pinned(O.tokens));
+    if (!text_direct)
+        for (int q = 0; q < (nsub > 1 ? 2 : 1); ++q)
+            if ((rc = pinned_need(c, c->h_tin[q], c->h_tin_cap[q], (size_t)bmax + 16))) return rc;
+    HostPool pool(pool_threads(c, dense_out ? (size_t)n_docs * (size_t)max_len * 8 : (size_t)tb));
+    alloc_site(c);
+    std::vector<uint32_t> row_first[3];                          // dense form: where each row of the slot's sub-batch starts among its entries
+    if (dense_out) {
+        for (auto& v : row_first) v.resize((size_t)nmax + 1);
+        if (c->opt.host_hints & 1) {
+            hint_huge(O.ids, (size_t)n_docs * (size_t)max_len * 4);
+            hint_huge(O.mask, (size_t)n_docs * (size_t)max_len * 4);
+        }
+    }
+    // whatever happens below, nothing of this call is in flight when it returns: the streams are drained, then the pool's threads
+    // finish what is queued and are joined (its destructor)
+    struct Drain { gz_ctx* c; ~Drain() { hipStreamSynchronize(c->s_in); hipStreamSynchronize(c->stream); hipStreamSynchronize(c->s_out); } } drain{c};
+
+    if ((rc = copy_in(c, c->w_toff.p, text_off, (size_t)(n_docs + 1) * 8, c->s_in))) return rc;
+    HIPCHK(c, hipMemsetAsync(c->w_flags.p, 0, 16, s));
+    const int32_t pad_id = c->dev.pad_id;
+    int64_t total = 0;
+    int ret = GZ_OK;
+    const int LAG = 2;                                           // sub-batches enqueued ahead of the one whose rows the host takes
+    for (int step = 0; step < nsub + LAG; ++step) {
+        if (step < nsub) {
+            // ---- sub-batch k: text in, kernels
+            const int k = step;
+            const int64_t lo = lo_of(k), hi = lo_of(k + 1);
+            const int64_t b0 = text_off[lo], b1 = text_off[hi];
+            if (b1 > b0) {
+                uint8_t* dst = (uint8_t*)c->w_text.p + (b0 - text_off[0]);
+                if (text_direct) HIPCHK(c, hipMemcpyAsync(dst, text + b0, (size_t)(b1 - b0), hipMemcpyHostToDevice, c->s_in));
+                else {
+                    uint8_t* h = c->h_tin[k & 1];
+                    if (k >= 2) HIPCHK(c, hipEventSynchronize(c->ev_in[k - 2]));        // (the copy that last read this buffer)
+                    const uint8_t* src = text + b0;
+                    pool.parallel((size_t)(b1 - b0), (size_t)1 << 20, [=](size_t a, size_t b) { std::memcpy(h + a, src + a, b - a); });
+                    HIPCHK(c, hipMemcpyAsync(dst, h, (size_t)(b1 - b0), hipMemcpyHostToDevice, c->s_in));
+                }
+            }
+            HIPCHK(c, hipEventRecord(c->ev_in[k], c->s_in));
+            GzAsmArgs A{};
+            A.n_texts = 1; A.n_docs = hi - lo; A.dense = 1; A.max_len = max_len;
+            A.ids = (int32_t*)c->w_csr_ids[k & 1].p; A.mask = (int32_t*)c->w_csr_mask[k & 1].p;
+            A.raw = nullptr; A.n_real = (int32_t*)c->w_csr_nreal.p + lo;
+            A.docs_per_wave = GZ_MAX_DOCS_PER_WAVE;
+            HIPCHK(c, hipStreamWaitEvent(s, c->ev_in[k], 0));
+            if ((rc = setup_text(c, c->tw[k & 1][0], c->w_tiny[k & 7][0], d_text + text_off[lo], d_off + lo, text_off[hi] - text_off[lo], A.n_docs, s, A.X[0]))) return rc;
+            gz_launch_pipeline_text(c->opt, T, c->dev, A.X[0], A.n_docs, use_words, (int32_t*)c->w_flags.p + 3, s, c->side, c->ev_sf0[k & 1][0], c->ev_sf[k & 1][0], c->ev_sj[k & 1][0]);
+            gz_launch_assemble(c->opt, T, A, s);
+            uint32_t* off32 = (uint32_t*)c->w_csr_off32.p;
+            gz_launch_row_offsets(A.n_real, A.n_docs, off32, s);
+            gz_launch_compact(A.ids, off32, A.n_docs, max_len, (uint8_t*)c->w_csr_comp.p + (size_t)bound[(size_t)k] * esz, bits, nullptr, s);
+            HIPCHK(c, hipMemcpyAsync(&c->h_tot[k], off32 + A.n_docs, 4, hipMemcpyDeviceToHost, s));
+            HIPCHK(c, hipEventRecord(c->ev_done[k], s));
+            HIPCHK(c, hipGetLastError());
+        }
+        if (step >= LAG) {
+            // ---- sub-batch j is compact: its entries come back
+            const int j = step - LAG;
+            const int64_t lo = lo_of(j), hi = lo_of(j + 1), nj = hi - lo;
+            HIPCHK(c, hipEventSynchronize(c->ev_done[j]));
+            const int64_t tk = c->h_tot[j];
+            const uint8_t* comp = (const uint8_t*)c->w_csr_comp.p + (size_t)bound[(size_t)j] * esz;
+            if (!dense_out && (ret != GZ_OK || total + tk > O.capacity)) { ret = GZ_E_CAPACITY; total += tk; continue; }
+            HIPCHK(c, hipStreamWaitEvent(c->s_out, c->ev_done[j], 0));
+            if (out_direct) {
+                if (tk) HIPCHK(c, hipMemcpyAsync((uint8_t*)O.tokens + (size_t)total * esz, comp, (size_t)tk * esz, hipMemcpyDeviceToHost, c->s_out));
+                HIPCHK(c, hipMemcpyAsync(O.n_real + lo, (int32_t*)c->w_csr_nreal.p + lo, (size_t)nj * 4, hipMemcpyDeviceToHost, c->s_out));
+                total += tk;
+                continue;
+            }
+            const int slot = j % 3;
+            pool.wait_tag(slot);                                 // (the jobs that read this slot two sub-batches ago)
+            const size_t ebytes = ((size_t)tk * esz + 15) & ~(size_t)15;
+            if ((rc = pinned_need(c, c->h_cout[slot], c->h_cout_cap[slot], ebytes + (size_t)nj * 4 + 16))) return rc;
+            uint8_t* hs = c->h_cout[slot];
+            if (tk) HIPCHK(c, hipMemcpyAsync(hs, comp, (size_t)tk * esz, hipMemcpyDeviceToHost, c->s_out));
+            HIPCHK(c, hipMemcpyAsync(hs + ebytes, (int32_t*)c->w_csr_nreal.p + lo, (size_t)nj * 4, hipMemcpyDeviceToHost, c->s_out));
+            HIPCHK(c, hipStreamSynchronize(c->s_out));
+            const int32_t* nr = (const int32_t*)(hs + ebytes);
+            if (!dense_out) {
+                uint8_t* dst = (uint8_t*)O.tokens + (size_t)total * esz;
+                const size_t nb = (size_t)tk * esz, parts = std::max<size_t>(1, std::min<size_t>((size_t)pool.threads(), nb >> 20));
+                for (size_t q = 0; q < parts; ++q) {
+                    const size_t a = nb * q / parts, b = nb * (q + 1) / parts;
+                    pool.submit(slot, [=] { std::memcpy(dst + a, hs + a, b - a); });
+                }
+                int32_t* nd = O.n_real + lo;
+                pool.submit(slot, [=] { std::memcpy(nd, nr, (size_t)nj * 4); });
+            } else {
+                uint32_t* rf = row_first[slot].data();
+                uint64_t acc = 0;
+                for (int64_t r = 0; r < nj; ++r) { rf[r] = (uint32_t)acc; acc += (uint32_t)(nr[r] < 0 ? 0 : nr[r] > max_len ? max_len : nr[r]); }
+                if (acc != (uint64_t)tk) return fail(c, GZ_E_HIP, "internal: the row lengths of a sub-batch add up to %llu entries, its compact rows hold %lld", (unsigned long long)acc, (long long)tk);
+                int32_t* ids = O.ids + lo * (int64_t)max_len;
+                int32_t* mask = O.mask + lo * (int64_t)max_len;
+                const int64_t per_job = std::max<int64_t>(1, ((int64_t)2 << 20) / ((int64_t)max_len * 4));       // ~ 2 MB of each array per job
+                for (int64_t r0 = 0; r0 < nj; r0 += per_job) {
+                    const int64_t r1 = std::min(nj, r0 + per_job);
+                    const bool populate = (c->opt.host_hints & 2) != 0;
+                    pool.submit(slot, [=] {
+                        if (populate) {
+                            hint_populate(ids + r0 * (int64_t)max_len, (size_t)(r1 - r0) * (size_t)max_len * 4);
+                            hint_populate(mask + r0 * (int64_t)max_len, (size_t)(r1 - r0) * (size_t)max_len * 4);
+                        }
+                        if (esz == 2) expand_rows_host((const uint16_t*)hs, rf, nr, r0, r1, max_len, pad_id, ids, mask);
+                        else expand_rows_host((const int32_t*)hs, rf, nr, r0, r1, max_len, pad_id, ids, mask);
+                    });
+                }
+                if (O.n_real) { int32_t* nd = O.n_real + lo; pool.submit(slot, [=] { std::memcpy(nd, nr, (size_t)nj * 4); }); }
+            }
+            total += tk;
+        }
+    }
+    pool.wait_all();
+    HIPCHK(c, hipStreamSynchronize(c->s_out));
+    HIPCHK(c, hipStreamSynchronize(s));
+    *total_out = total;
+    // a look-back time-out in any sub-batch (sub-batches of 32 MB are exactly the size that takes the chained scan)
+    HIPCHK(c, hipMemcpy(c->h_flags, c->w_flags.p, 8, hipMemcpyDeviceToHost));
+    if (c->h_flags[0]) return fail(c, GZ_E_HIP, "internal: a chained scan (gz_scan32m_kernel look-back) timed out");
+    if (ret) return fail(c, ret, "the batch has %lld real entries, capacity is %lld", (long long)total, (long long)O.capacity);
+    return GZ_OK;
 }
+
 
 static int encode_host_locked(gz_ctx* c, const uint8_t* text, const int64_t* text_off, const uint8_t* pair,
                     const int64_t* pair_off, int64_t n_docs, int32_t max_len, uint32_t flags, int64_t capacity,
@@ -1241,24 +1559,40 @@ static int encode_host_locked(gz_ctx* c, const uint8_t* text, const int64_t* tex
     const int64_t tb = text_off[n_docs] - text_off[0];
     const int64_t pb = is_pair ? pair_off[n_docs] - pair_off[0] : 0;
     int rc;
+    // Large dense calls of single texts -- the batch form of Tokenize.__call__(text, max_len=L) -- bring only the rows' real
+    // entries over the bus and pad them into the caller's arrays on host threads (csr_core); the switch dense_csr = 0, timed
+    // calls, kept word records and the load-time whole-word build take the plain path below.
+    if (dense && !is_pair && c->opt.dense_csr && !(flags & (GZ_TIMING | GZ_KEEP_WORDS)) && !c->building_words) {
+        CsrOut O;
+        O.ids = input_ids; O.mask = attention_mask; O.n_real = n_real;
+        int64_t total = 0;
+        if ((rc = csr_core(c, text, text_off, n_docs, max_len, flags, ids_fit_16(c) ? 16 : 32, O, &total))) return rc;
+        if (row_off) for (int64_t i = 0; i <= n_docs; ++i) row_off[i] = i * (int64_t)max_len;
+        if (status) std::memset(status, 0, (size_t)n_docs * 4);
+        return GZ_OK;
+    }
     if ((rc = ensure(c, c->w_text, (size_t)tb + 16))) return rc;
     if ((rc = ensure(c, c->w_toff, (size_t)(n_docs + 1) * 8))) return rc;
-    if (tb) HIPCHK(c, hipMemcpyAsync(c->w_text.p, text + text_off[0], (size_t)tb, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemcpyAsync(c->w_toff.p, text_off, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice, s));
-    const uint8_t* d_text = (const uint8_t*)c->w_text.p - text_off[0];
-    const uint8_t* d_pair = nullptr;
-    if (is_pair) {
-        if ((rc = ensure(c, c->w_pair, (size_t)pb + 16))) return rc;
-        if ((rc = ensure(c, c->w_poff, (size_t)(n_docs + 1) * 8))) return rc;
-        if (pb) HIPCHK(c, hipMemcpyAsync(c->w_pair.p, pair + pair_off[0], (size_t)pb, hipMemcpyHostToDevice, s));
-        HIPCHK(c, hipMemcpyAsync(c->w_poff.p, pair_off, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice, s));
-        d_pair = (const uint8_t*)c->w_pair.p - pair_off[0];
-    }
     // device-side outputs: dense -> n_docs*max_len; ragged -> worst case is known only after the encode kernel,
     // so size them by the bound  rows <= max(raw tokens, max_len)  with raw tokens <= bytes + 2 (+2)
     const int64_t raw_elems = tb + pb + (is_pair ? 4 : 2) * n_docs;
     int64_t out_elems = dense ? n_docs * (int64_t)max_len : raw_elems;
     if (!dense && S.pad_mode && max_len > 0) out_elems += n_docs * (int64_t)max_len;
+    HostPool pool(pool_threads(c, (size_t)tb + (size_t)pb + (size_t)out_elems * (is_pair ? 16 : 8)));
+    {
+        const uint8_t* src = text + text_off[0];
+        if (tb && (rc = copy_in(c, c->w_text.p, src, (size_t)tb, s))) return rc;
+    }
+    if ((rc = copy_in(c, c->w_toff.p, text_off, (size_t)(n_docs + 1) * 8, s))) return rc;
+    const uint8_t* d_text = (const uint8_t*)c->w_text.p - text_off[0];
+    const uint8_t* d_pair = nullptr;
+    if (is_pair) {
+        if ((rc = ensure(c, c->w_pair, (size_t)pb + 16))) return rc;
+        if ((rc = ensure(c, c->w_poff, (size_t)(n_docs + 1) * 8))) return rc;
+        if (pb && (rc = copy_in(c, c->w_pair.p, pair + pair_off[0], (size_t)pb, s))) return rc;
+        if ((rc = copy_in(c, c->w_poff.p, pair_off, (size_t)(n_docs + 1) * 8, s))) return rc;
+        d_pair = (const uint8_t*)c->w_pair.p - pair_off[0];
+    }
     if ((rc = ensure(c, c->w_ids, (size_t)out_elems * 4 + 16))) return rc;
     if ((rc = ensure(c, c->w_mask, (size_t)out_elems * 4 + 16))) return rc;
     if ((rc = ensure(c, c->w_nreal, (size_t)(n_docs + 1) * 4))) return rc;
@@ -1268,82 +1602,79 @@ static int encode_host_locked(gz_ctx* c, const uint8_t* text, const int64_t* tex
         if ((rc = ensure(c, c->w_seq, (size_t)out_elems * 4 + 16))) return rc;
         if ((rc = ensure(c, c->w_pairlen, (size_t)(n_docs + 1) * 8))) return rc;
     }
-    DBuf st2;   // status needs its own buffer in ragged mode (w_status holds the raw counts there)
-    if (is_pair) { if ((rc = ensure(c, st2, (size_t)(n_docs + 1) * 4))) return rc; }
+    // status needs its own buffer in ragged mode (w_status holds the raw counts there)
+    struct Scratch { DBuf b; ~Scratch() { release(b); } } st2;
+    if (is_pair) { if ((rc = ensure(c, st2.b, (size_t)(n_docs + 1) * 4))) return rc; }
     rc = encode_device_locked(c, d_text, (const int64_t*)c->w_toff.p, d_pair, is_pair ? (const int64_t*)c->w_poff.p : nullptr,
                               n_docs, max_len, flags, out_elems, (int32_t*)c->w_ids.p, (int32_t*)c->w_mask.p,
                               is_pair ? (int32_t*)c->w_tt.p : nullptr, is_pair ? (int32_t*)c->w_seq.p : nullptr,
                               (int64_t*)c->w_rowoff.p, is_pair ? (int32_t*)c->w_pairlen.p : nullptr,
-                              (int32_t*)c->w_nreal.p, is_pair ? (int32_t*)st2.p : nullptr, text_off, pair_off);
+                              (int32_t*)c->w_nreal.p, is_pair ? (int32_t*)st2.b.p : nullptr, text_off, pair_off);
     if (rc == GZ_OK) rc = sync_locked(c);
-    if (rc) { release(st2); return rc; }
+    if (rc) return rc;
 
     int64_t total = n_docs * (int64_t)max_len;
     if (!dense) {
-        HIPCHK(c, hipMemcpy(row_off, c->w_rowoff.p, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost));
+        if ((rc = copy_out(c, row_off, c->w_rowoff.p, (size_t)(n_docs + 1) * 8, s, &pool))) return rc;
         total = row_off[n_docs];
-        if (total > capacity) { release(st2); return fail(c, GZ_E_CAPACITY, "ragged output needs %lld entries, capacity is %lld", (long long)total, (long long)capacity); }
+        if (total > capacity) return fail(c, GZ_E_CAPACITY, "ragged output needs %lld entries, capacity is %lld", (long long)total, (long long)capacity);
     } else if (row_off) {
         for (int64_t i = 0; i <= n_docs; ++i) row_off[i] = i * (int64_t)max_len;
     }
     if (total) {
-        HIPCHK(c, hipMemcpy(input_ids, c->w_ids.p, (size_t)total * 4, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(attention_mask, c->w_mask.p, (size_t)total * 4, hipMemcpyDeviceToHost));
+        if ((size_t)total * 4 >= ((size_t)64 << 20) && (c->opt.host_hints & 1)) { hint_huge(input_ids, (size_t)total * 4); hint_huge(attention_mask, (size_t)total * 4); }
+        if ((rc = copy_out(c, input_ids, c->w_ids.p, (size_t)total * 4, s, &pool))) return rc;
+        if ((rc = copy_out(c, attention_mask, c->w_mask.p, (size_t)total * 4, s, &pool))) return rc;
         if (is_pair) {
-            HIPCHK(c, hipMemcpy(token_type_ids, c->w_tt.p, (size_t)total * 4, hipMemcpyDeviceToHost));
-            HIPCHK(c, hipMemcpy(sequence_id, c->w_seq.p, (size_t)total * 4, hipMemcpyDeviceToHost));
+            if ((rc = copy_out(c, token_type_ids, c->w_tt.p, (size_t)total * 4, s, &pool))) return rc;
+            if ((rc = copy_out(c, sequence_id, c->w_seq.p, (size_t)total * 4, s, &pool))) return rc;
         }
     }
     if (is_pair) {
-        HIPCHK(c, hipMemcpy(pair_len, c->w_pairlen.p, (size_t)n_docs * 8, hipMemcpyDeviceToHost));
-        HIPCHK(c, hipMemcpy(status, st2.p, (size_t)n_docs * 4, hipMemcpyDeviceToHost));
+        if ((rc = copy_out(c, pair_len, c->w_pairlen.p, (size_t)n_docs * 8, s, &pool))) return rc;
+        if ((rc = copy_out(c, status, st2.b.p, (size_t)n_docs * 4, s, &pool))) return rc;
     } else if (status) {
         std::memset(status, 0, (size_t)n_docs * 4);
     }
-    if (n_real) HIPCHK(c, hipMemcpy(n_real, c->w_nreal.p, (size_t)n_docs * 4, hipMemcpyDeviceToHost));
-    release(st2);
+    if (n_real && (rc = copy_out(c, n_real, c->w_nreal.p, (size_t)n_docs * 4, s, &pool))) return rc;
     return GZ_OK;
 }
+
 
 int gz_encode_batch(gz_ctx* c, const uint8_t* text, const int64_t* text_off, const uint8_t* pair,
                     const int64_t* pair_off, int64_t n_docs, int32_t max_len, uint32_t flags, int64_t capacity,
                     int32_t* input_ids, int32_t* attention_mask, int32_t* token_type_ids, int32_t* sequence_id,
                     int64_t* row_off, int32_t* pair_len, int32_t* n_real, int32_t* status)
-{
+try {
     if (!c) return GZ_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     return encode_host_locked(c, text, text_off, pair, pair_off, n_docs, max_len, flags, capacity, input_ids,
                               attention_mask, token_type_ids, sequence_id, row_off, pair_len, n_real, status);
-}
+} GZ_CATCH(c)
 
 int gz_host_alloc(gz_ctx* c, size_t bytes, void** ptr)
-{
+try {
     if (!c || !ptr) return GZ_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
     hipError_t e = hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault);
     if (e != hipSuccess) { *ptr = nullptr; return fail(c, GZ_E_NOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
     return GZ_OK;
-}
+} GZ_CATCH(c)
 
 int gz_host_free(gz_ctx* c, void* ptr)
-{
+try {
     // Independent of the context's state on purpose: a pinned block may outlive the context that allocated it (a numpy
     // array finalized after Tokenize.close(), or at interpreter exit), so nothing of *c is touched; c may be NULL.
     (void)c;
     if (ptr && hipHostFree(ptr) != hipSuccess) return GZ_E_HIP;
     return GZ_OK;
-}
+} GZ_CATCH(c)
 
-// Host buffers in, CSR out, copies overlapped with the kernels.  The batch is cut into sub-batches of documents:
-//   copy-in stream : text of sub-batch k+1 travels while
-//   main stream    : the pipeline of sub-batch k runs (dense rows into one of two device slots), then the rows lose
-//                    their padding (scan of n_real + gz_compact_kernel) into the sub-batch's region of a device buffer,
-//   copy-out stream: the real entries of sub-batch k-1 travel back, straight to their final place in the caller's array.
-// What crosses PCIe is the text, 8 bytes per document of offsets, and 2 (or 4) bytes per real token + 4 per document.
+// Host buffers in, CSR out, copies overlapped with the kernels (csr_core above).
 int gz_encode_batch_csr(gz_ctx* c, const uint8_t* text, const int64_t* text_off, int64_t n_docs, int32_t max_len, uint32_t flags,
                         void* tokens, int64_t capacity, int32_t bits, int32_t* n_real, int64_t* total_out)
-{
+try {
     if (!c) return GZ_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
@@ -1357,106 +1688,15 @@ int gz_encode_batch_csr(gz_ctx* c, const uint8_t* text, const int64_t* text_off,
         if (text_off[i + 1] < text_off[i]) return fail(c, GZ_E_INVALID, "text_off is not non-decreasing at %lld", (long long)i);
     *total_out = 0;
     if (n_docs == 0) return GZ_OK;
-    const int64_t tb = text_off[n_docs] - text_off[0];
-    if (tb > 0 && !text) return fail(c, GZ_E_INVALID, "text is NULL");
-    if (c->pend.active) { int rc0 = sync_locked(c); if (rc0) return rc0; }
-    if (c->x_used) HIPCHK(c, hipStreamSynchronize(c->xstream));
-    if (!c->s_in) {
-        HIPCHK(c, hipStreamCreateWithFlags(&c->s_in, hipStreamNonBlocking));
-        HIPCHK(c, hipStreamCreateWithFlags(&c->s_out, hipStreamNonBlocking));
-        for (auto& e : c->ev_in) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        for (auto& e : c->ev_done) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        HIPCHK(c, hipHostMalloc((void**)&c->h_tot, sizeof(uint32_t) * gz_ctx::CSR_SUBS, hipHostMallocDefault));
-    }
-    // sub-batches of about 32 MB of text (equal document counts), at most CSR_SUBS
-    int nsub = (int)((tb + (32ll << 20) - 1) / (32ll << 20));
-    if (nsub < 1) nsub = 1;
-    if (nsub > gz_ctx::CSR_SUBS) nsub = gz_ctx::CSR_SUBS;
-    if ((int64_t)nsub > n_docs) nsub = (int)n_docs;
-    const size_t esz = bits == 16 ? 2 : 4;
-    int64_t nmax = 0;
-    for (int k = 0; k < nsub; ++k) { const int64_t lo = (int64_t)k * n_docs / nsub, hi = (int64_t)(k + 1) * n_docs / nsub; if (hi - lo > nmax) nmax = hi - lo; }
-    // a document of b bytes has at most min(max_len, b + 2) entries: regions of the device compact buffer start at these bounds
-    std::vector<int64_t> bound((size_t)nsub + 1, 0);
-    for (int k = 0; k < nsub; ++k) {
-        const int64_t lo = (int64_t)k * n_docs / nsub, hi = (int64_t)(k + 1) * n_docs / nsub;
-        const int64_t by_bytes = (text_off[hi] - text_off[lo]) + 2 * (hi - lo), by_rows = (hi - lo) * (int64_t)max_len;
-        int64_t b = by_bytes < by_rows ? by_bytes : by_rows;
-        b = (b + 7) & ~(int64_t)7;                                          // regions stay 16-byte aligned for either entry size
-        bound[(size_t)k + 1] = bound[(size_t)k] + b;
-    }
-    int rc;
-    if ((rc = ensure(c, c->w_text, (size_t)tb + 16)) || (rc = ensure(c, c->w_toff, (size_t)(n_docs + 1) * 8)) ||
-        (rc = ensure(c, c->w_csr_nreal, (size_t)(n_docs + 1) * 4)) || (rc = ensure(c, c->w_csr_off32, (size_t)(nmax + 2) * 4)) ||
-        (rc = ensure(c, c->w_csr_comp, (size_t)bound[(size_t)nsub] * esz + 64)))
-        return rc;
-    for (int q = 0; q < (nsub > 1 ? 2 : 1); ++q)
-        if ((rc = ensure(c, c->w_csr_ids[q], (size_t)nmax * (size_t)max_len * 4 + 64)) || (rc = ensure(c, c->w_csr_mask[q], (size_t)nmax * (size_t)max_len * 4 + 64)))
-            return rc;
-    const GzDeviceTables* T = (const GzDeviceTables*)c->t_struct.p;
-    const uint8_t* d_text = (const uint8_t*)c->w_text.p - text_off[0];
-    const int64_t* d_off = (const int64_t*)c->w_toff.p;
-    const int use_words = use_words_flags(c, flags);
-    hipStream_t s = c->stream;
-    if ((rc = need_side_streams(c, false))) return rc;
-    // ---- everything the GPU has to do is enqueued first ...
-    HIPCHK(c, hipMemcpyAsync(c->w_toff.p, text_off, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice, c->s_in));
-    for (int k = 0; k < nsub; ++k) {
-        const int64_t lo = (int64_t)k * n_docs / nsub, hi = (int64_t)(k + 1) * n_docs / nsub;
-        const int64_t b0 = text_off[lo], b1 = text_off[hi];
-        if (b1 > b0) HIPCHK(c, hipMemcpyAsync((uint8_t*)c->w_text.p + (b0 - text_off[0]), text + b0, (size_t)(b1 - b0), hipMemcpyHostToDevice, c->s_in));
-        HIPCHK(c, hipEventRecord(c->ev_in[k], c->s_in));
-    }
-    HIPCHK(c, hipMemsetAsync(c->w_flags.p, 0, 16, s));
-    for (int k = 0; k < nsub; ++k) {
-        const int64_t lo = (int64_t)k * n_docs / nsub, hi = (int64_t)(k + 1) * n_docs / nsub;
-        GzAsmArgs A{};
-        A.n_texts = 1; A.n_docs = hi - lo; A.dense = 1; A.max_len = max_len;
-        A.ids = (int32_t*)c->w_csr_ids[k & 1].p; A.mask = (int32_t*)c->w_csr_mask[k & 1].p;
-        A.raw = nullptr; A.n_real = (int32_t*)c->w_csr_nreal.p + lo;
-        A.docs_per_wave = GZ_MAX_DOCS_PER_WAVE;
-        HIPCHK(c, hipStreamWaitEvent(s, c->ev_in[k], 0));
-        if ((rc = setup_text(c, c->tw[k & 1][0], c->w_tiny[k & 7][0], d_text + text_off[lo], d_off + lo, text_off[hi] - text_off[lo], A.n_docs, s, A.X[0]))) {
-            // copies from / to the caller's buffers are in flight: let them finish before the caller gets its buffers back
-            hipStreamSynchronize(c->s_in); hipStreamSynchronize(s); hipStreamSynchronize(c->s_out);
-            return rc;
-        }
-        gz_launch_pipeline_text(c->opt, T, c->dev, A.X[0], A.n_docs, use_words, (int32_t*)c->w_flags.p + 3, s, c->side, c->ev_sf0[k & 1][0], c->ev_sf[k & 1][0], c->ev_sj[k & 1][0]);
-        gz_launch_assemble(c->opt, T, A, s);
-        uint32_t* off32 = (uint32_t*)c->w_csr_off32.p;
-        gz_launch_row_offsets(A.n_real, A.n_docs, off32, s);
-        gz_launch_compact(A.ids, off32, A.n_docs, max_len, (uint8_t*)c->w_csr_comp.p + (size_t)bound[(size_t)k] * esz, bits, nullptr, s);
-        HIPCHK(c, hipMemcpyAsync(&c->h_tot[k], off32 + A.n_docs, 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(c, hipEventRecord(c->ev_done[k], s));
-    }
-    HIPCHK(c, hipGetLastError());
-    // ... then the host follows the sub-batches: as soon as one is compact, its entries go to their final place
-    int64_t total = 0;
-    int ret = GZ_OK;
-    for (int k = 0; k < nsub; ++k) {
-        const int64_t lo = (int64_t)k * n_docs / nsub, hi = (int64_t)(k + 1) * n_docs / nsub;
-        HIPCHK(c, hipEventSynchronize(c->ev_done[k]));
-        const int64_t tk = c->h_tot[k];
-        if (ret == GZ_OK && total + tk <= capacity) {
-            HIPCHK(c, hipStreamWaitEvent(c->s_out, c->ev_done[k], 0));
-            if (tk) HIPCHK(c, hipMemcpyAsync((uint8_t*)tokens + (size_t)total * esz, (uint8_t*)c->w_csr_comp.p + (size_t)bound[(size_t)k] * esz,
-                                             (size_t)tk * esz, hipMemcpyDeviceToHost, c->s_out));
-            HIPCHK(c, hipMemcpyAsync(n_real + lo, (int32_t*)c->w_csr_nreal.p + lo, (size_t)(hi - lo) * 4, hipMemcpyDeviceToHost, c->s_out));
-        } else ret = GZ_E_CAPACITY;
-        total += tk;
-    }
-    HIPCHK(c, hipStreamSynchronize(c->s_out));
-    HIPCHK(c, hipStreamSynchronize(s));
-    *total_out = total;
-    // a look-back time-out in any sub-batch (sub-batches of 32 MB are exactly the size that takes the chained scan)
-    HIPCHK(c, hipMemcpy(c->h_flags, c->w_flags.p, 8, hipMemcpyDeviceToHost));
-    if (c->h_flags[0]) return fail(c, GZ_E_HIP, "internal: a chained scan (gz_scan32m_kernel look-back) timed out");
-    if (ret) return fail(c, ret, "the batch has %lld real entries, capacity is %lld", (long long)total, (long long)capacity);
-    return GZ_OK;
-}
+    if (text_off[n_docs] - text_off[0] > 0 && !text) return fail(c, GZ_E_INVALID, "text is NULL");
+    CsrOut O;
+    O.tokens = tokens; O.capacity = capacity; O.n_real = n_real;
+    return csr_core(c, text, text_off, n_docs, max_len, flags, bits, O, total_out);
+} GZ_CATCH(c)
+
 
 int gz_word_token_counts(gz_ctx* c, int which_text, int32_t* counts, int64_t capacity, int64_t* doc_first, int64_t* n_words)
-{
+try {
     if (!c || !counts || !doc_first || !n_words || which_text < 0 || which_text > 1) return c ? fail(c, GZ_E_INVALID, "bad arguments") : GZ_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
@@ -1468,18 +1708,21 @@ int gz_word_token_counts(gz_ctx* c, int which_text, int32_t* counts, int64_t cap
     int64_t wbase = 0, dbase = 0;
     for (const GzAsmArgs& S : subs) {
         const GzTextBufs& X = S.X[which_text];
+        int rcs;
+        alloc_site(c);
         std::vector<uint32_t> dw((size_t)S.n_docs + 1);
-        HIPCHK(c, hipMemcpy(dw.data(), X.docw0, dw.size() * 4, hipMemcpyDeviceToHost));
+        if ((rcs = copy_out(c, dw.data(), X.docw0, dw.size() * 4, c->stream))) return rcs;
         uint32_t total = 0;                                      // the scanned block counts end with the word total
-        HIPCHK(c, hipMemcpy(&total, X.blkcnt + X.nblk, 4, hipMemcpyDeviceToHost));
+        if ((rcs = copy_out_small(c, &total, X.blkcnt + X.nblk, 4, c->stream))) return rcs;
         for (int64_t d = 0; d < S.n_docs; ++d) doc_first[dbase + d] = wbase + dw[(size_t)d];
         if (wbase + (int64_t)total > capacity) {
             *n_words = wbase + total;
             return fail(c, GZ_E_CAPACITY, "the batch has more than %lld words", (long long)capacity);
         }
         if (total) {
+            alloc_site(c);
             std::vector<uint32_t> wt(total);
-            HIPCHK(c, hipMemcpy(wt.data(), X.wtok, (size_t)total * 4, hipMemcpyDeviceToHost));
+            if ((rcs = copy_out(c, wt.data(), X.wtok, (size_t)total * 4, c->stream))) return rcs;
             for (uint32_t w = 0; w < total; ++w) counts[wbase + w] = !(wt[w] & 0x80000000u) ? 1 : (wt[w] & 0x20000000u) ? (int32_t)((wt[w] >> 25) & 15u) + 1 : (int32_t)(wt[w] & 0x0FFFFFFFu);   // (record forms: gz_pipeline.inc, W_NEAR)
         }
         wbase += total; dbase += S.n_docs;
@@ -1487,10 +1730,10 @@ int gz_word_token_counts(gz_ctx* c, int which_text, int32_t* counts, int64_t cap
     doc_first[dbase] = wbase;
     *n_words = wbase;
     return GZ_OK;
-}
+} GZ_CATCH(c)
 
 int64_t gz_bpe_word(gz_ctx* c, const uint8_t* word, int64_t len, int32_t* pieces, int64_t cap)
-{
+try {
     if (!c) return GZ_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
@@ -1502,7 +1745,7 @@ int64_t gz_bpe_word(gz_ctx* c, const uint8_t* word, int64_t len, int32_t* pieces
     if ((rc = ensure(c, c->w_wordout, (size_t)len * 4 + 16))) return rc;
     if ((rc = ensure(c, c->w_arena, (size_t)len * 4 + 16))) return rc;
     hipStream_t s = c->stream;
-    HIPCHK(c, hipMemcpyAsync(c->w_word.p, word, (size_t)len, hipMemcpyHostToDevice, s));
+    if ((rc = copy_in(c, c->w_word.p, word, (size_t)len, s))) return rc;
     gz_launch_bpe_word((const GzDeviceTables*)c->t_struct.p, (const uint8_t*)c->w_word.p, len, (uint32_t*)c->w_arena.p, (int32_t*)c->w_wordout.p,
                        (int32_t)len, (int32_t*)c->w_flags.p + 2, s);
     HIPCHK(c, hipMemcpyAsync(c->h_flags + 2, (int32_t*)c->w_flags.p + 2, 4, hipMemcpyDeviceToHost, s));
@@ -1510,49 +1753,64 @@ int64_t gz_bpe_word(gz_ctx* c, const uint8_t* word, int64_t len, int32_t* pieces
     HIPCHK(c, hipGetLastError());
     const int64_t n = c->h_flags[2];
     if (n > cap) return fail(c, GZ_E_CAPACITY, "word has %lld pieces, capacity %lld", (long long)n, (long long)cap);
-    HIPCHK(c, hipMemcpy(pieces, c->w_wordout.p, (size_t)n * 4, hipMemcpyDeviceToHost));
+    if ((rc = copy_out(c, pieces, c->w_wordout.p, (size_t)n * 4, s))) return rc;
     for (int64_t i = 0; i < n; ++i) {
         const uint32_t v = (uint32_t)pieces[i];
         if (v & GZ_SYM_UNKNOWN) pieces[i] = -(int32_t)(v & 0x1FFFFFu) - 1;
     }
     return n;
-}
+} GZ_CATCH(c)
 
 int gz_device_alloc(gz_ctx* c, size_t bytes, void** dptr)
-{
+try {
     if (!c || !dptr) return GZ_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
+#ifdef GZ_DIAG
+    // (guard mode: the caller's buffers -- the text it uploads, the rows it reads back -- end at an unmapped granule too: what the
+    //  device entry points may touch of a caller's buffer is exactly the bytes the caller said it has)
+    if (c->opt.diag_guard) { *dptr = nullptr; return guard_alloc(c, dptr, bytes ? bytes : 16, c->opt.diag_guard); }
+#endif
     hipError_t e = hipMalloc(dptr, bytes + 256);
     if (e != hipSuccess) { *dptr = nullptr; return fail(c, GZ_E_NOMEM, "hipMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
     return GZ_OK;
-}
+} GZ_CATCH(c)
 
 int gz_device_free(gz_ctx* c, void* dptr)
-{
+try {
     if (!c) return GZ_E_INVALID;
     HIPCHK(c, hipSetDevice(c->device));
+#ifdef GZ_DIAG
+    if (dptr && guard_free(dptr)) return GZ_OK;
+#endif
     if (dptr) HIPCHK(c, hipFree(dptr));
     return GZ_OK;
-}
+} GZ_CATCH(c)
 
 int gz_memcpy_h2d(gz_ctx* c, void* dst, const void* src, size_t bytes)
-{
-    if (!c) return GZ_E_INVALID;
+try {
+    if (!c || (bytes && (!dst || !src))) return c ? fail(c, GZ_E_INVALID, "bad arguments") : GZ_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
-    if (bytes) HIPCHK(c, hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    // (through the library's pinned buffers, on the context's stream; complete on return: device entry points read their inputs on
+    //  other streams as well)
+    int rc = copy_in(c, dst, src, bytes, c->stream);
+    if (rc) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     return GZ_OK;
-}
+} GZ_CATCH(c)
 
 int gz_memcpy_d2h(gz_ctx* c, void* dst, const void* src, size_t bytes)
-{
-    if (!c) return GZ_E_INVALID;
+try {
+    if (!c || (bytes && (!dst || !src))) return c ? fail(c, GZ_E_INVALID, "bad arguments") : GZ_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
-    if (bytes) HIPCHK(c, hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
-    return GZ_OK;
-}
+    if (c->x_used) HIPCHK(c, hipStreamSynchronize(c->xstream));       // (what an exchange step wrote is complete too)
+    HostPool pool(pool_threads(c, bytes));
+    return copy_out(c, dst, src, bytes, c->stream, &pool);
+} GZ_CATCH(c)
 
 int gz_timing_history(gz_ctx* c, double* out_ms, int32_t max, int32_t* n_out)
-{
+try {
     if (!c || !out_ms || !n_out || max < 0) return GZ_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
@@ -1568,14 +1826,14 @@ int gz_timing_history(gz_ctx* c, double* out_ms, int32_t max, int32_t* n_out)
     *n_out = n;
     c->ring_n = 0;
     return GZ_OK;
-}
+} GZ_CATCH(c)
 
 int gz_timing(gz_ctx* c, double out_ms[4])
-{
+try {
     if (!c || !out_ms) return GZ_E_INVALID;
     for (int i = 0; i < 4; ++i) out_ms[i] = c->timing[i];
     return GZ_OK;
-}
+} GZ_CATCH(c)
 
 // ---- batch decode ----------------------------------------------------------------------------------------------------
 namespace {
@@ -1606,10 +1864,10 @@ int dec_set_unk(gz_ctx* c, const uint8_t* unk, int32_t unk_len)
     if (unk_len < 0 || (size_t)unk_len > GZ_DEC_UNK_MAX) return fail(c, GZ_E_LIMIT, "unk string longer than %zu bytes", GZ_DEC_UNK_MAX);
     const std::string u((const char*)unk, (size_t)unk_len);
     if (c->dec_unk_set && u == c->dec_unk) return GZ_OK;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    if (unk_len) HIPCHK(c, hipMemcpy((uint8_t*)c->t_dec_bytes.p + c->dec_bytes_len, unk, (size_t)unk_len, hipMemcpyHostToDevice));
+    int rcs;
+    if (unk_len && (rcs = copy_in(c, (uint8_t*)c->t_dec_bytes.p + c->dec_bytes_len, unk, (size_t)unk_len, c->stream))) return rcs;
     const GzDecEntry e = dec_entry_of(u, c->dec_bytes_len);
-    HIPCHK(c, hipMemcpy((GzDecEntry*)c->t_dec_entries.p + c->dec_n_ids, &e, sizeof e, hipMemcpyHostToDevice));
+    if ((rcs = copy_in(c, (GzDecEntry*)c->t_dec_entries.p + c->dec_n_ids, &e, sizeof e, c->stream))) return rcs;
     c->dec_unk = u;
     c->dec_unk_set = true;
     return GZ_OK;
@@ -1627,9 +1885,12 @@ int decode_device_locked(gz_ctx* c, const int32_t* ids_dev, const int64_t* row_o
     GzDecTable D{(const GzDecEntry*)c->t_dec_entries.p, (const uint8_t*)c->t_dec_bytes.p, c->dec_n_ids};
     gz_launch_decode(D, ids_dev, row_off_dev, n_rows, (int64_t*)c->w_dec_rb.p, out_off_dev, nullptr, 0, c->stream);
     *total = 0;
-    if (n_rows > 0) HIPCHK(c, hipMemcpyAsync(total, out_off_dev + n_rows, 8, hipMemcpyDeviceToHost, c->stream));
+    int64_t* const h_total = reinterpret_cast<int64_t*>(reinterpret_cast<uint8_t*>(c->h_pick) + 256);       // (pinned scratch)
+    *h_total = 0;
+    if (n_rows > 0) HIPCHK(c, hipMemcpyAsync(h_total, out_off_dev + n_rows, 8, hipMemcpyDeviceToHost, c->stream));
     else HIPCHK(c, hipMemsetAsync(out_off_dev, 0, 8, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    *total = *h_total;
     if (!out_dev) return GZ_OK;
     if (*total > capacity) return fail(c, GZ_E_CAPACITY, "decode needs %lld bytes, capacity is %lld", (long long)*total, (long long)capacity);
     gz_launch_decode(D, ids_dev, row_off_dev, n_rows, nullptr, out_off_dev, out_dev, capacity, c->stream);
@@ -1640,7 +1901,7 @@ int decode_device_locked(gz_ctx* c, const int32_t* ids_dev, const int64_t* row_o
 }  // namespace
 
 int gz_decoder_snapshot(gz_ctx* c)
-{
+try {
     if (!c) return GZ_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mu);
     if (!c->have_tables) return fail(c, GZ_E_NOTABLES, "gz_load_tables has not been called");
@@ -1664,27 +1925,28 @@ int gz_decoder_snapshot(gz_ctx* c)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     if ((rc = ensure(c, c->t_dec_entries, ent.size() * sizeof(GzDecEntry)))) return rc;
     if ((rc = ensure(c, c->t_dec_bytes, bytes.size() + GZ_DEC_UNK_MAX + 16))) return rc;
-    HIPCHK(c, hipMemcpy(c->t_dec_entries.p, ent.data(), ent.size() * sizeof(GzDecEntry), hipMemcpyHostToDevice));
-    if (!bytes.empty()) HIPCHK(c, hipMemcpy(c->t_dec_bytes.p, bytes.data(), bytes.size(), hipMemcpyHostToDevice));
+    if ((rc = copy_in(c, c->t_dec_entries.p, ent.data(), ent.size() * sizeof(GzDecEntry), c->stream))) return rc;
+    if (!bytes.empty() && (rc = copy_in(c, c->t_dec_bytes.p, bytes.data(), bytes.size(), c->stream))) return rc;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
     c->dec_n_ids = n_ids;
     c->dec_bytes_len = bytes.size();
     c->dec_unk_set = false;
     c->have_dec = true;
     return GZ_OK;
-}
+} GZ_CATCH(c)
 
 int gz_decode_batch_device(gz_ctx* c, const int32_t* ids_dev, const int64_t* row_off_dev, int64_t n_rows, const uint8_t* unk,
                            int32_t unk_len, uint8_t* out_dev, int64_t capacity, int64_t* out_off_dev, int64_t* total_host)
-{
+try {
     if (!c || !row_off_dev || !out_off_dev || !total_host || n_rows < 0 || (!unk && unk_len) || capacity < 0)
         return c ? fail(c, GZ_E_INVALID, "bad arguments") : GZ_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mu);
     return decode_device_locked(c, ids_dev, row_off_dev, n_rows, unk, unk_len, out_dev, capacity, out_off_dev, total_host);
-}
+} GZ_CATCH(c)
 
 int gz_decode_batch(gz_ctx* c, const int32_t* ids, const int64_t* row_off, int64_t n_rows, const uint8_t* unk, int32_t unk_len,
                     uint8_t* out, int64_t capacity, int64_t* out_off)
-{
+try {
     if (!c || !row_off || !out_off || n_rows < 0 || (!unk && unk_len) || capacity < 0 || (capacity > 0 && !out))
         return c ? fail(c, GZ_E_INVALID, "bad arguments") : GZ_E_INVALID;
     const int64_t n_ids = row_off[n_rows] - row_off[0];
@@ -1696,23 +1958,25 @@ int gz_decode_batch(gz_ctx* c, const int32_t* ids, const int64_t* row_off, int64
     if ((rc = ensure(c, c->w_dec_ids, (size_t)(n_ids + 1) * 4))) return rc;
     if ((rc = ensure(c, c->w_dec_roff, (size_t)(n_rows + 1) * 8))) return rc;
     if ((rc = ensure(c, c->w_dec_ooff, (size_t)(n_rows + 1) * 8))) return rc;
-    if (n_ids) HIPCHK(c, hipMemcpyAsync(c->w_dec_ids.p, ids + row_off[0], (size_t)n_ids * 4, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->w_dec_roff.p, row_off, (size_t)(n_rows + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    if (n_ids && (rc = copy_in(c, c->w_dec_ids.p, ids + row_off[0], (size_t)n_ids * 4, c->stream))) return rc;
+    if ((rc = copy_in(c, c->w_dec_roff.p, row_off, (size_t)(n_rows + 1) * 8, c->stream))) return rc;
     int64_t total = 0;
     if ((rc = decode_device_locked(c, (const int32_t*)c->w_dec_ids.p - row_off[0], (const int64_t*)c->w_dec_roff.p, n_rows, unk, unk_len, nullptr, 0,
                                    (int64_t*)c->w_dec_ooff.p, &total))) return rc;
-    HIPCHK(c, hipMemcpy(out_off, c->w_dec_ooff.p, (size_t)(n_rows + 1) * 8, hipMemcpyDeviceToHost));
+    if ((rc = copy_out(c, out_off, c->w_dec_ooff.p, (size_t)(n_rows + 1) * 8, c->stream))) return rc;
     if (total > capacity) return fail(c, GZ_E_CAPACITY, "decode needs %lld bytes, capacity is %lld", (long long)total, (long long)capacity);
     if (total == 0) return GZ_OK;
     if ((rc = ensure(c, c->w_dec_out, (size_t)total))) return rc;
     GzDecTable D{(const GzDecEntry*)c->t_dec_entries.p, (const uint8_t*)c->t_dec_bytes.p, c->dec_n_ids};
     gz_launch_decode(D, (const int32_t*)c->w_dec_ids.p - row_off[0], (const int64_t*)c->w_dec_roff.p, n_rows, nullptr, (int64_t*)c->w_dec_ooff.p,
                      (uint8_t*)c->w_dec_out.p, total, c->stream);
-    HIPCHK(c, hipMemcpyAsync(out, c->w_dec_out.p, (size_t)total, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
+    {
+        HostPool pool(pool_threads(c, (size_t)total));
+        if ((rc = copy_out(c, out, c->w_dec_out.p, (size_t)total, c->stream, &pool))) return rc;
+    }
     HIPCHK(c, hipGetLastError());
     return GZ_OK;
-}
+} GZ_CATCH(c)
 
 // ---- text pre-pass ----------------------------------------------------------------------------------------------------
 namespace {
@@ -1761,10 +2025,12 @@ int preprocess_device_locked(gz_ctx* c, const int32_t* ops, int32_t n_ops, const
             HIPCHK(c, hipMemset(c->w_pplb.p, 0, c->w_pplb.cap));
         }
         gz_launch_pp_tail(F.out, off_dev, F.out_len32, n_docs, out_dev, capacity, out_off_dev, (unsigned long long*)c->w_pplb.p, ctl, c->lb_epoch + 1, c->stream);
-        uint32_t h[4] = {0, 0, 0, 0}, total32 = 0;
+        uint32_t* const h = reinterpret_cast<uint32_t*>(reinterpret_cast<uint8_t*>(c->h_pick) + 272);       // (pinned scratch: 4 control words + the total)
+        for (int q = 0; q < 5; ++q) h[q] = 0;
         HIPCHK(c, hipMemcpyAsync(h, ctl, 16, hipMemcpyDeviceToHost, c->stream));
-        HIPCHK(c, hipMemcpyAsync(&total32, F.out_len32 + n_docs, 4, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipMemcpyAsync(h + 4, F.out_len32 + n_docs, 4, hipMemcpyDeviceToHost, c->stream));
         HIPCHK(c, hipStreamSynchronize(c->stream));
+        const uint32_t total32 = h[4];
         if (h[2]) return fail(c, GZ_E_HIP, "internal: the chained scan of the pre-pass timed out");
         if (h[0] == 0) {
             *total = (int64_t)total32;
@@ -1787,8 +2053,11 @@ int preprocess_device_locked(gz_ctx* c, const int32_t* ops, int32_t n_ops, const
     }
     gz_launch_scan64(in_len, n_docs, out_off_dev, c->stream);
     *total = 0;
-    if (n_docs > 0) HIPCHK(c, hipMemcpyAsync(total, out_off_dev + n_docs, 8, hipMemcpyDeviceToHost, c->stream));
+    int64_t* const h_total = reinterpret_cast<int64_t*>(reinterpret_cast<uint8_t*>(c->h_pick) + 320);       // (pinned scratch)
+    *h_total = 0;
+    if (n_docs > 0) HIPCHK(c, hipMemcpyAsync(h_total, out_off_dev + n_docs, 8, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    *total = *h_total;
     if (!out_dev) return GZ_OK;
     if (*total > capacity) return fail(c, GZ_E_CAPACITY, "pre-pass output needs %lld bytes, capacity is %lld", (long long)*total, (long long)capacity);
     gz_launch_pp_pack(in, off_dev, in_len, n_docs, out_dev, out_off_dev, c->stream);
@@ -1801,16 +2070,16 @@ int preprocess_device_locked(gz_ctx* c, const int32_t* ops, int32_t n_ops, const
 int gz_preprocess_batch_device(gz_ctx* c, const int32_t* ops, int32_t n_ops, const uint8_t* text_dev, const int64_t* text_off_dev,
                                int64_t n_docs, int64_t text_bytes, uint8_t* out_dev, int64_t capacity, int64_t* out_off_dev,
                                int64_t* total_host)
-{
+try {
     if (!c || !ops || n_ops < 1 || n_ops > 16 || !text_off_dev || !out_off_dev || !total_host || n_docs < 0 || text_bytes < 0 || capacity < 0)
         return c ? fail(c, GZ_E_INVALID, "bad arguments") : GZ_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mu);
     return preprocess_device_locked(c, ops, n_ops, text_dev, text_off_dev, n_docs, text_bytes, out_dev, capacity, out_off_dev, total_host);
-}
+} GZ_CATCH(c)
 
 int gz_preprocess_batch(gz_ctx* c, const int32_t* ops, int32_t n_ops, const uint8_t* text, const int64_t* text_off, int64_t n_docs,
                         uint8_t* out, int64_t capacity, int64_t* out_off)
-{
+try {
     if (!c || !ops || n_ops < 1 || n_ops > 16 || !text_off || !out_off || n_docs < 0 || capacity < 0 || (capacity > 0 && !out))
         return c ? fail(c, GZ_E_INVALID, "bad arguments") : GZ_E_INVALID;
     const int64_t nbytes = text_off[n_docs] - text_off[0];
@@ -1825,16 +2094,17 @@ int gz_preprocess_batch(gz_ctx* c, const int32_t* ops, int32_t n_ops, const uint
     DBuf& fino = c->w_dec_ooff;
     if ((rc = ensure(c, fin, (size_t)nbytes + 16))) return rc;
     if ((rc = ensure(c, fino, (size_t)(n_docs + 1) * 8))) return rc;
-    if (nbytes) HIPCHK(c, hipMemcpyAsync(c->w_pp_in.p, text + text_off[0], (size_t)nbytes, hipMemcpyHostToDevice, c->stream));
-    HIPCHK(c, hipMemcpyAsync(c->w_pp_inoff.p, text_off, (size_t)(n_docs + 1) * 8, hipMemcpyHostToDevice, c->stream));
+    if (nbytes && (rc = copy_in(c, c->w_pp_in.p, text + text_off[0], (size_t)nbytes, c->stream))) return rc;
+    if ((rc = copy_in(c, c->w_pp_inoff.p, text_off, (size_t)(n_docs + 1) * 8, c->stream))) return rc;
     int64_t total = 0;
     if ((rc = preprocess_device_locked(c, ops, n_ops, (const uint8_t*)c->w_pp_in.p - text_off[0], (const int64_t*)c->w_pp_inoff.p, n_docs, nbytes,
                                        (uint8_t*)fin.p, nbytes, (int64_t*)fino.p, &total))) return rc;
-    HIPCHK(c, hipMemcpy(out_off, fino.p, (size_t)(n_docs + 1) * 8, hipMemcpyDeviceToHost));
+    HostPool pool(pool_threads(c, (size_t)total));
+    if ((rc = copy_out(c, out_off, fino.p, (size_t)(n_docs + 1) * 8, c->stream, &pool))) return rc;
     if (total > capacity) return fail(c, GZ_E_CAPACITY, "pre-pass output needs %lld bytes, capacity is %lld", (long long)total, (long long)capacity);
-    if (total) HIPCHK(c, hipMemcpy(out, fin.p, (size_t)total, hipMemcpyDeviceToHost));
+    if (total && (rc = copy_out(c, out, fin.p, (size_t)total, c->stream, &pool))) return rc;
     return GZ_OK;
-}
+} GZ_CATCH(c)
 
 // ---- DLPack hand-off ---------------------------------------------------------------------------------------------------
 // The deleter a consumer (torch, ...) calls may run while the Python interpreter shuts down, so it must be plain C:
@@ -1853,7 +2123,7 @@ struct DlManagedTensor { DlTensor dl_tensor; void* manager_ctx; void (*deleter)(
 void block_release(gz_block* b)
 {
     if (b && b->refs.fetch_sub(1) == 1) {
-        if (b->dptr) hipFree(b->dptr);
+        if (b->dptr) dev_free(b->dptr);
         delete b;
     }
 }
@@ -1867,19 +2137,19 @@ void dl_deleter(DlManagedTensor* mt)
 }  // namespace
 
 int gz_block_create(gz_ctx* c, void* dptr, gz_block** out)
-{
+try {
     if (!c || !dptr || !out) return c ? fail(c, GZ_E_INVALID, "bad arguments") : GZ_E_INVALID;
     gz_block* b = new (std::nothrow) gz_block();
     if (!b) return fail(c, GZ_E_NOMEM, "out of memory");
     b->dptr = dptr; b->device = c->device;
     *out = b;
     return GZ_OK;
-}
+} GZ_CATCH(c)
 
 void gz_block_release(gz_block* b) { block_release(b); }
 
 void* gz_block_dlpack(gz_block* b, int32_t ndim, const int64_t* shape, int32_t dtype_code, int32_t dtype_bits)
-{
+try {
     if (!b || ndim < 0 || ndim > 8 || (ndim && !shape)) return nullptr;
     DlManagedTensor* mt = (DlManagedTensor*)calloc(1, sizeof(DlManagedTensor));
     int64_t* sh = (int64_t*)malloc(sizeof(int64_t) * (size_t)(ndim ? ndim : 1));
@@ -1896,13 +2166,13 @@ void* gz_block_dlpack(gz_block* b, int32_t ndim, const int64_t* shape, int32_t d
     mt->manager_ctx = b;
     mt->deleter = dl_deleter;
     return mt;
-}
+} GZ_CATCH_NULL
 
 // PyCapsule destructor for a capsule made from gz_block_dlpack's result: a capsule that was never consumed (its name is
 // still "dltensor"; a consumer renames it to "used_dltensor" and takes over the deleter) releases its reference to
 // the block.  Plain C, resolved against the running interpreter: this library does not link libpython.
 void gz_dlpack_capsule_destructor(void* capsule)
-{
+try {
     typedef int (*isvalid_t)(void*, const char*);
     typedef void* (*getptr_t)(void*, const char*);
     static const isvalid_t isvalid = (isvalid_t)dlsym(RTLD_DEFAULT, "PyCapsule_IsValid");
@@ -1910,7 +2180,7 @@ void gz_dlpack_capsule_destructor(void* capsule)
     if (!capsule || !isvalid || !getptr || !isvalid(capsule, "dltensor")) return;
     DlManagedTensor* mt = (DlManagedTensor*)getptr(capsule, "dltensor");
     if (mt && mt->deleter) mt->deleter(mt);
-}
+} GZ_CATCH_VOID
 
 // ---- compact rows for the exchange step -----------------------------------------------------------------------------
 namespace {
@@ -1937,9 +2207,10 @@ int compact_impl(gz_ctx* c, const int32_t* rows_dev, const int32_t* n_real_dev, 
     return GZ_OK;
 }
 int expand_impl(gz_ctx* c, const void* compact_dev, int bits, const int32_t* n_real_dev, int64_t n_rows, int32_t row_len,
-                int32_t* ids_dev, int32_t* mask_dev, const uint32_t* first_dev = nullptr /* a block's own array: no scan */)
+                int32_t* ids_dev, int32_t* mask_dev, const uint32_t* first_dev = nullptr /* a block's own array: no scan */,
+                int64_t total = 0xFFFFFFFFll /* entries the compact array holds (a block's announced total) */)
 {
-    if (!c || !compact_dev || !n_real_dev || !ids_dev || !mask_dev || n_rows < 0 || row_len <= 0)
+    if (!c || !compact_dev || !n_real_dev || !ids_dev || !mask_dev || n_rows < 0 || row_len <= 0 || total < 0 || total > 0xFFFFFFFFll)
         return c ? fail(c, GZ_E_INVALID, "bad arguments") : GZ_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mu);
     if (!c->have_tables) return fail(c, GZ_E_NOTABLES, "gz_load_tables has not been called");
@@ -1952,7 +2223,11 @@ int expand_impl(gz_ctx* c, const void* compact_dev, int bits, const int32_t* n_r
     }
     if ((rc = x_begin(c))) return rc;
     if (!first_dev) gz_launch_row_offsets(n_real_dev, n_rows, (uint32_t*)c->w_rowoff32.p, c->xstream);
-    gz_launch_expand(compact_dev, bits, off, n_real_dev, n_rows, row_len, c->dev.pad_id, ids_dev, mask_dev, c->xstream);
+    // (a row that does not fit its block raises w_flags[12]; the word travels to the pinned scratch behind every expansion and is
+    //  reported -- and cleared -- by the next synchronisation: sync_locked)
+    int32_t* bad = (int32_t*)c->w_flags.p + 12;
+    gz_launch_expand(compact_dev, bits, off, n_real_dev, n_rows, row_len, c->dev.pad_id, ids_dev, mask_dev, (uint32_t)total, bad, c->xstream);
+    HIPCHK(c, hipMemcpyAsync(reinterpret_cast<uint8_t*>(c->h_pick) + 384, bad, 4, hipMemcpyDeviceToHost, c->xstream));
     if ((rc = x_end(c))) return rc;
     HIPCHK(c, hipGetLastError());
     return GZ_OK;
@@ -1961,35 +2236,35 @@ int expand_impl(gz_ctx* c, const void* compact_dev, int bits, const int32_t* n_r
 
 int gz_compact_rows(gz_ctx* c, const int32_t* rows_dev, const int32_t* n_real_dev, int64_t n_rows, int32_t row_len,
                     int32_t* out_dev, int64_t* total_host)
-{
+try {
     return compact_impl(c, rows_dev, n_real_dev, n_rows, row_len, out_dev, 32, total_host);
-}
+} GZ_CATCH(c)
 int gz_compact_rows16(gz_ctx* c, const int32_t* rows_dev, const int32_t* n_real_dev, int64_t n_rows, int32_t row_len,
                       uint16_t* out_dev, int64_t* total_host)
-{
+try {
     return compact_impl(c, rows_dev, n_real_dev, n_rows, row_len, out_dev, 16, total_host);
-}
+} GZ_CATCH(c)
 int gz_expand_rows(gz_ctx* c, const int32_t* compact_dev, const int32_t* n_real_dev, int64_t n_rows, int32_t row_len,
                    int32_t* ids_dev, int32_t* mask_dev)
-{
+try {
     return expand_impl(c, compact_dev, 32, n_real_dev, n_rows, row_len, ids_dev, mask_dev);
-}
+} GZ_CATCH(c)
 int gz_expand_rows16(gz_ctx* c, const uint16_t* compact_dev, const int32_t* n_real_dev, int64_t n_rows, int32_t row_len,
                      int32_t* ids_dev, int32_t* mask_dev)
-{
+try {
     return expand_impl(c, compact_dev, 16, n_real_dev, n_rows, row_len, ids_dev, mask_dev);
-}
+} GZ_CATCH(c)
 
 int gz_encode_emit_block(gz_ctx* c, int32_t* block_dev, int32_t bits)
-{
+try {
     if (!c || (bits != 16 && bits != 32)) return c ? fail(c, GZ_E_INVALID, "bad arguments") : GZ_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mu);
     if (block_dev && bits == 16 && (!c->have_tables || !ids_fit_16(c))) return fail(c, GZ_E_LIMIT, "the vocabulary has ids that do not fit 16 bits");
     c->emit_block = block_dev; c->emit_bits = bits;              // (null: disarm)
     return GZ_OK;
-}
+} GZ_CATCH(c)
 int gz_block_total(gz_ctx* c, int32_t back, int64_t* total_host)
-{
+try {
     if (!c || !total_host || back < 0 || back > 2) return c ? fail(c, GZ_E_INVALID, "bad arguments") : GZ_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mu);
     if (c->enc_seq <= (uint64_t)back) return fail(c, GZ_E_INVALID, "no encode call %d calls back", back);
@@ -1999,11 +2274,11 @@ int gz_block_total(gz_ctx* c, int32_t back, int64_t* total_host)
     HIPCHK(c, hipEventSynchronize(c->ev_blk[slot]));
     *total_host = reinterpret_cast<uint32_t*>(c->h_pick)[56 + slot];
     return GZ_OK;
-}
+} GZ_CATCH(c)
 
 int gz_compact_block(gz_ctx* c, const int32_t* rows_dev, const int32_t* n_real_dev, int64_t n_rows, int32_t row_len, int32_t bits,
                      int32_t* block_dev, int64_t* total_host)
-{
+try {
     if (!c || !block_dev || !n_real_dev || n_rows < 0 || (bits != 16 && bits != 32)) return c ? fail(c, GZ_E_INVALID, "bad arguments") : GZ_E_INVALID;
     {
         // the row lengths in front of the entries (on the exchange stream, behind the encode call they belong to)
@@ -2015,24 +2290,24 @@ int gz_compact_block(gz_ctx* c, const int32_t* rows_dev, const int32_t* n_real_d
         if ((rc = x_end(c))) return rc;
     }
     return compact_impl(c, rows_dev, n_real_dev, n_rows, row_len, block_dev + 2 * n_rows, bits, total_host, (uint32_t*)(block_dev + n_rows));
-}
-int gz_expand_block(gz_ctx* c, const int32_t* block_dev, int32_t bits, int64_t n_rows, int32_t row_len, int32_t* ids_dev, int32_t* mask_dev)
-{
+} GZ_CATCH(c)
+int gz_expand_block(gz_ctx* c, const int32_t* block_dev, int32_t bits, int64_t n_rows, int32_t row_len, int64_t total_entries, int32_t* ids_dev, int32_t* mask_dev)
+try {
     if (!c || !block_dev || n_rows < 0 || (bits != 16 && bits != 32)) return c ? fail(c, GZ_E_INVALID, "bad arguments") : GZ_E_INVALID;
-    return expand_impl(c, block_dev + 2 * n_rows, bits, block_dev, n_rows, row_len, ids_dev, mask_dev, (const uint32_t*)(block_dev + n_rows));
-}
+    return expand_impl(c, block_dev + 2 * n_rows, bits, block_dev, n_rows, row_len, ids_dev, mask_dev, (const uint32_t*)(block_dev + n_rows), total_entries);
+} GZ_CATCH(c)
 
 // ---- multi-GPU exchange step --------------------------------------------------------------------------------------
 int gz_comm_unique_id(uint8_t id_out[128])
-{
+try {
     if (!id_out) return GZ_E_INVALID;
     if (!rccl_load()) return fail(nullptr, GZ_E_RCCL, "librccl.so could not be loaded");
     int r = g_rccl.GetUniqueId(id_out);
     return r == 0 ? GZ_OK : fail(nullptr, GZ_E_RCCL, "ncclGetUniqueId failed (%d)", r);
-}
+} GZ_CATCH(nullptr)
 
 int gz_comm_init(gz_ctx* c, const uint8_t id[128], int rank, int world)
-{
+try {
     if (!c || !id || world < 1 || rank < 0 || rank >= world) return c ? fail(c, GZ_E_INVALID, "bad arguments") : GZ_E_INVALID;
     if (!rccl_load()) return fail(c, GZ_E_RCCL, "librccl.so could not be loaded");
     std::lock_guard<std::mutex> lk(c->mu);
@@ -2044,19 +2319,19 @@ int gz_comm_init(gz_ctx* c, const uint8_t id[128], int rank, int world)
     if (r != 0) { c->comm = nullptr; return fail(c, GZ_E_RCCL, "ncclCommInitRank: %s", g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "error"); }
     c->rank = rank; c->world = world;
     return GZ_OK;
-}
+} GZ_CATCH(c)
 
 int gz_exchange_select(gz_ctx* c, int back)
-{
+try {
     if (!c || back < 0 || back > 2) return c ? fail(c, GZ_E_INVALID, "back must be 0, 1 or 2") : GZ_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mu);
     c->x_back = back;
     return GZ_OK;
-}
+} GZ_CATCH(c)
 
 int gz_gather_rows(gz_ctx* c, const int32_t* send_dev, int64_t n_rows_local, int32_t row_len, int32_t* recv_dev,
                    const int64_t* rows_per_rank, int root)
-{
+try {
     if (!c) return GZ_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mu);
     if (!c->comm) return fail(c, GZ_E_RCCL, "gz_comm_init has not been called");
@@ -2113,10 +2388,10 @@ int gz_gather_rows(gz_ctx* c, const int32_t* send_dev, int64_t n_rows_local, int
     c->xring_n++;
     { int rc1 = x_end(c); if (rc1) return rc1; }
     return GZ_OK;
-}
+} GZ_CATCH(c)
 
 int gz_exchange_timing_history(gz_ctx* c, double* out_ms, int32_t max, int32_t* n_out)
-{
+try {
     if (!c || !out_ms || !n_out || max < 0) return GZ_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
@@ -2132,6 +2407,6 @@ int gz_exchange_timing_history(gz_ctx* c, double* out_ms, int32_t max, int32_t* 
     *n_out = n;
     c->xring_n = 0;
     return GZ_OK;
-}
+} GZ_CATCH(c)
 
 }  // extern "C"

@@ -75,8 +75,15 @@ struct GzOptions {
     int32_t ph_force_overflow = 0;    // k > 0: the perfect-hash builder refuses every k-th bucket (overflow paths of the kernels)
     int32_t ph_hot_slots = 1024;      // slots at the head of the whole-word table reserved for the most frequent words (0 .. 8192)
     int32_t word_weights = 0;         // frequency estimate of whole words: 0 auto, 1 the vocab file's counts, 2 merge ranks
+    // ---- the host paths (gz_api.cpp)
+    int32_t host_threads = 0;         // threads that move a large host call's rows into the caller's arrays (0: by the host's processors, at most 16)
+    int32_t dense_csr = 1;            // 1: a large dense single-text host call brings only the rows' real entries over the bus and pads them on the host; 0: the dense rows cross
+    int32_t host_hints = 3;           // fresh output arrays of a large host call: bit 0 MADV_HUGEPAGE on them, bit 1 MADV_POPULATE_WRITE per piece before it is written
+    int32_t inject_bad_alloc = 0;     // test hook: k > 0 makes the k-th allocation site reached from now on throw std::bad_alloc (counts down to 0)
     // ---- diagnostic build only (results are WRONG with ablate / rows_dbg)
     int32_t diag_poison = 0, rows_dpw = 0, rows_dbg = 0, ablate = 0;
+    int32_t diag_guard = 0;           // device buffers from a guard-granule allocator: 1 the buffer ENDS at the last byte of its mapping (an unmapped granule behind it),
+                                      // 2 it STARTS at the first byte (an unmapped granule before it); no slack behind a buffer in either mode
 };
 GzOptions& gz_default_options();                                          // gz_host_api.cpp
 int gz_option_set(GzOptions& o, const char* key, int64_t value);           // GZ_OK, or GZ_E_INVALID for an unknown key / a value out of range

@@ -1,0 +1,262 @@
+// Host side of the host entry points (included by gz_api.cpp, after gz_ctx / fail / HIPCHK / ensure): how bytes get from the
+// caller's memory to the device and back.
+//
+// RULE: memory the CALLER owns is never handed to a HIP copy.  A caller's buffer is, as a rule, pageable (a numpy array, a
+// std::vector): the runtime would pin it on the fly, or stage it through buffers of its own, inside the copy call -- slow
+// (2 GB of dense rows came back at 15 GB/s), serialised with everything else, and a code path of the runtime that only host
+// calls on fresh allocations ever take.  Here every copy between host and device has a PINNED buffer of this library on the host
+// side; the caller's memory is read and written by plain host code (memcpy, or the row expansion below) on worker threads,
+// while the next piece is on the bus.  Memory that came from gz_host_alloc is pinned already and is copied directly.
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <thread>
+#include <sched.h>
+#include <sys/mman.h>
+#include <unistd.h>
+
+namespace {
+
+constexpr size_t XFER_CHUNK = (size_t)4 << 20;       // pinned transfer buffers: two of these (grown on demand up to this size)
+
+// ---- how many worker threads a host call may use: the processors this process may run on (affinity mask, cgroup quota), at
+// most 32 -- the work is first-touch page faults and streaming stores: more threads than that gain nothing.
+int host_cpus()
+{
+    static const int n = [] {
+        int k = 0;
+        cpu_set_t set;
+        if (sched_getaffinity(0, sizeof set, &set) == 0) k = CPU_COUNT(&set);
+        if (k <= 0) k = (int)sysconf(_SC_NPROCESSORS_ONLN);
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[32] = {0};
+            long long period = 0;
+            if (fscanf(f, "%31s %lld", q, &period) == 2 && q[0] != 'm' && period > 0) {
+                const long long quota = atoll(q);
+                const int by_quota = (int)((quota + period - 1) / period);
+                if (by_quota >= 1 && by_quota < k) k = by_quota;
+            }
+            fclose(f);
+        }
+        return k < 1 ? 1 : k > 32 ? 32 : k;
+    }();
+    return n;
+}
+
+// ---- a few worker threads for the length of ONE host call (made by the call, joined before it returns: nothing of the library
+// runs when no call is in progress).  Jobs carry a tag (the pinned slot they read); wait_tag() returns when no job of that tag is
+// queued or running.  With 0 threads submit() runs the job on the caller's thread.
+class HostPool {
+public:
+    explicit HostPool(int n_threads)
+    {
+        for (int i = 0; i < n_threads; ++i) th_.emplace_back([this] { run(); });
+    }
+    ~HostPool()
+    {
+        { std::lock_guard<std::mutex> lk(m_); stop_ = true; }
+        cv_.notify_all();
+        for (std::thread& t : th_) t.join();
+    }
+    HostPool(const HostPool&) = delete;
+    HostPool& operator=(const HostPool&) = delete;
+    int threads() const { return (int)th_.size(); }
+    void submit(int tag, std::function<void()> f)
+    {
+        if (th_.empty()) { f(); return; }
+        { std::lock_guard<std::mutex> lk(m_); q_.emplace_back(tag, std::move(f)); ++busy_[tag & 7]; }
+        cv_.notify_one();
+    }
+    void wait_tag(int tag)
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        done_.wait(lk, [&] { return busy_[tag & 7] == 0; });
+    }
+    void wait_all() { for (int t = 0; t < 8; ++t) wait_tag(t); }
+    // [0, n) cut into pieces of at least `grain`, one job each, all finished on return
+    template <class F>
+    void parallel(size_t n, size_t grain, F f)
+    {
+        const size_t parts = th_.empty() ? 1 : std::max<size_t>(1, std::min<size_t>((size_t)th_.size(), n / (grain ? grain : 1)));
+        if (parts <= 1) { if (n) f((size_t)0, n); return; }
+        for (size_t p = 0; p < parts; ++p) {
+            const size_t lo = n * p / parts, hi = n * (p + 1) / parts;
+            submit(7, [=] { f(lo, hi); });
+        }
+        wait_tag(7);
+    }
+private:
+    void run()
+    {
+        for (;;) {
+            std::pair<int, std::function<void()>> job;
+            {
+                std::unique_lock<std::mutex> lk(m_);
+                cv_.wait(lk, [&] { return stop_ || !q_.empty(); });
+                if (q_.empty()) return;
+                job = std::move(q_.front());
+                q_.pop_front();
+            }
+            job.second();
+            { std::lock_guard<std::mutex> lk(m_); --busy_[job.first & 7]; }
+            done_.notify_all();
+        }
+    }
+    std::vector<std::thread> th_;
+    std::mutex m_;
+    std::condition_variable cv_, done_;
+    std::deque<std::pair<int, std::function<void()>>> q_;
+    int busy_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool stop_ = false;
+};
+
+int pool_threads(gz_ctx* c, size_t bytes_to_move)
+{
+    int t = c->opt.host_threads > 0 ? c->opt.host_threads : host_cpus();
+    const size_t by_size = bytes_to_move / ((size_t)8 << 20);         // a thread per 8 MB: small calls stay on the caller's thread
+    if ((size_t)t > by_size) t = (int)by_size;
+    return t <= 1 ? 0 : t;
+}
+
+// Is this host pointer page-locked memory the runtime knows (gz_host_alloc)?  Unknown pointers make the query fail: the error is
+// taken off the runtime's per-thread slot again.
+bool is_pinned(const void* p)
+{
+    if (!p) return false;
+    hipPointerAttribute_t a;
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
+    return a.type == hipMemoryTypeHost;
+}
+
+int pinned_need(gz_ctx* c, uint8_t*& p, size_t& cap, size_t bytes)
+{
+    if (bytes <= cap && p) return GZ_OK;
+    if (p) { hipHostFree(p); p = nullptr; cap = 0; }
+    size_t want = bytes + bytes / 4 + 4096;
+    hipError_t e = hipHostMalloc((void**)&p, want, hipHostMallocDefault);
+    if (e != hipSuccess) { p = nullptr; return fail(c, GZ_E_NOMEM, "hipHostMalloc(%zu): %s", want, hipGetErrorString(e)); }
+    cap = want;
+    return GZ_OK;
+}
+
+int xfer_need(gz_ctx* c, size_t bytes)
+{
+    const size_t want = bytes < XFER_CHUNK ? (bytes < 65536 ? 65536 : bytes) : XFER_CHUNK;
+    for (int b = 0; b < 2; ++b) {
+        if (c->xfer_busy[b]) { HIPCHK(c, hipEventSynchronize(c->ev_xfer[b])); c->xfer_busy[b] = false; }
+        if (c->h_xfer_cap[b] < want) {
+            if (c->h_xfer[b]) { hipHostFree(c->h_xfer[b]); c->h_xfer[b] = nullptr; c->h_xfer_cap[b] = 0; }
+            const size_t cap = want >= XFER_CHUNK / 2 ? XFER_CHUNK : want * 2;
+            if (hipHostMalloc((void**)&c->h_xfer[b], cap, hipHostMallocDefault) != hipSuccess) { c->h_xfer[b] = nullptr; return fail(c, GZ_E_NOMEM, "pinned transfer buffer (%zu bytes)", cap); }
+            c->h_xfer_cap[b] = cap;
+        }
+        if (!c->ev_xfer[b]) HIPCHK(c, hipEventCreateWithFlags(&c->ev_xfer[b], hipEventDisableTiming));
+    }
+    return GZ_OK;
+}
+
+// Host -> device, ordered on stream s.  On return the bytes have LEFT src (the caller may reuse it); they may still be on their
+// way to the device.
+int copy_in(gz_ctx* c, void* dst_dev, const void* src_host, size_t bytes, hipStream_t s)
+{
+    if (!bytes) return GZ_OK;
+    if (bytes >= 65536 && is_pinned(src_host)) {
+        HIPCHK(c, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, s));
+        return GZ_OK;
+    }
+    int rc = xfer_need(c, bytes);
+    if (rc) return rc;
+    const size_t chunk = std::min(c->h_xfer_cap[0], c->h_xfer_cap[1]);
+    int b = 0;
+    for (size_t o = 0; o < bytes; o += chunk, b ^= 1) {
+        const size_t n = std::min(chunk, bytes - o);
+        if (c->xfer_busy[b]) { HIPCHK(c, hipEventSynchronize(c->ev_xfer[b])); c->xfer_busy[b] = false; }
+        std::memcpy(c->h_xfer[b], (const uint8_t*)src_host + o, n);
+        HIPCHK(c, hipMemcpyAsync((uint8_t*)dst_dev + o, c->h_xfer[b], n, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipEventRecord(c->ev_xfer[b], s));
+        c->xfer_busy[b] = true;
+    }
+    return GZ_OK;
+}
+
+// Device -> host, behind whatever stream s holds.  Every byte is in dst on return.  Piece k + 1 is on the bus while piece k is
+// copied out of its pinned buffer (by the pool's threads when there is one).
+int copy_out(gz_ctx* c, void* dst_host, const void* src_dev, size_t bytes, hipStream_t s, HostPool* pool = nullptr)
+{
+    if (!bytes) return GZ_OK;
+    if (bytes >= 65536 && is_pinned(dst_host)) {
+        HIPCHK(c, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        return GZ_OK;
+    }
+    int rc = xfer_need(c, bytes);                               // (both buffers are idle after this)
+    if (rc) return rc;
+    const size_t chunk = std::min(c->h_xfer_cap[0], c->h_xfer_cap[1]);
+    const size_t pieces = (bytes + chunk - 1) / chunk;
+    auto issue = [&](size_t k) -> int {
+        const size_t o = k * chunk, n = std::min(chunk, bytes - o);
+        HIPCHK(c, hipMemcpyAsync(c->h_xfer[k & 1], (const uint8_t*)src_dev + o, n, hipMemcpyDeviceToHost, s));
+        HIPCHK(c, hipEventRecord(c->ev_xfer[k & 1], s));
+        return GZ_OK;
+    };
+    if ((rc = issue(0))) return rc;
+    for (size_t k = 0; k < pieces; ++k) {
+        HIPCHK(c, hipEventSynchronize(c->ev_xfer[k & 1]));
+        if (k + 1 < pieces && (rc = issue(k + 1))) return rc;
+        const size_t o = k * chunk, n = std::min(chunk, bytes - o);
+        uint8_t* d = (uint8_t*)dst_host + o;
+        const uint8_t* h = c->h_xfer[k & 1];
+        if (pool && pool->threads()) pool->parallel(n, (size_t)256 << 10, [=](size_t lo, size_t hi) { std::memcpy(d + lo, h + lo, hi - lo); });
+        else std::memcpy(d, h, n);
+    }
+    return GZ_OK;
+}
+
+// a few bytes (a total, a flag word) from the device, through the context's pinned scratch words
+int copy_out_small(gz_ctx* c, void* dst_host, const void* src_dev, size_t bytes, hipStream_t s)
+{
+    if (bytes > 64) return copy_out(c, dst_host, src_dev, bytes, s);
+    uint8_t* h = reinterpret_cast<uint8_t*>(c->h_pick) + 448;           // (h_pick is 512 bytes: [0, 256) the picks and block totals, [256, 512) scratch)
+    HIPCHK(c, hipMemcpyAsync(h, src_dev, bytes, hipMemcpyDeviceToHost, s));
+    HIPCHK(c, hipStreamSynchronize(s));
+    std::memcpy(dst_host, h, bytes);
+    return GZ_OK;
+}
+
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23
+#endif
+// The arrays a large call fills are, as a rule, fresh allocations nobody has touched: every 4-KiB page of them costs a page
+// fault at its first store.  Two hints, both harmless where they do not apply (errors are ignored): the range may be backed by
+// huge pages (one fault per 2 MiB where the system allows it), and a piece about to be written is populated by ONE system call
+// instead of a fault per page.
+void hint_huge(void* p, size_t bytes)
+{
+    const uintptr_t lo = ((uintptr_t)p + 0x1FFFFF) & ~(uintptr_t)0x1FFFFF, hi = ((uintptr_t)p + bytes) & ~(uintptr_t)0x1FFFFF;
+    if (hi > lo) (void)madvise((void*)lo, hi - lo, MADV_HUGEPAGE);
+}
+void hint_populate(void* p, size_t bytes)
+{
+    const uintptr_t lo = ((uintptr_t)p + 4095) & ~(uintptr_t)4095, hi = ((uintptr_t)p + bytes) & ~(uintptr_t)4095;
+    if (hi > lo) (void)madvise((void*)lo, hi - lo, MADV_POPULATE_WRITE);
+}
+
+// CSR rows -> dense [rows, max_len] int32 ids + mask in the caller's arrays: rows [r0, r1) of a sub-batch whose entries lie in
+// `tok` (16- or 32-bit) from row_first[r] on.  Padding with the pad id (tokenize.py:141-146), mask = ids != pad (:148-152).
+template <typename E>
+void expand_rows_host(const E* tok, const uint32_t* row_first, const int32_t* n_real, int64_t r0, int64_t r1, int32_t max_len, int32_t pad,
+                      int32_t* ids, int32_t* mask)
+{
+    for (int64_t r = r0; r < r1; ++r) {
+        const E* src = tok + row_first[r];
+        int32_t n = n_real[r];
+        if (n < 0) n = 0;
+        if (n > max_len) n = max_len;
+        int32_t* di = ids + r * (int64_t)max_len;
+        int32_t* dm = mask + r * (int64_t)max_len;
+        for (int32_t i = 0; i < n; ++i) { const int32_t v = (int32_t)src[i]; di[i] = v; dm[i] = v != pad; }
+        for (int32_t i = n; i < max_len; ++i) { di[i] = pad; dm[i] = 0; }
+    }
+}
+
+}  // namespace

@@ -91,7 +91,7 @@ void gz_launch_compact(const int32_t* rows, const uint32_t* off, int64_t n_rows,
                        hipStream_t s);
 // row r: n_real[r] entries from first[r] on (scanned offsets, or a block's own array: the rows then lie in any order)
 void gz_launch_expand(const void* compact, int bits, const uint32_t* first, const int32_t* n_real, int64_t n_rows, int32_t row_len, int32_t pad_id,
-                      int32_t* ids, int32_t* mask, hipStream_t s);
+                      int32_t* ids, int32_t* mask, uint32_t total /* entries the compact array holds */, int32_t* bad /* set when a row does not fit */, hipStream_t s);
 void gz_launch_assemble(const GzOptions& O, const GzDeviceTables* T_dev, const GzAsmArgs& A, hipStream_t s);
 void gz_launch_rows_ragged(const GzDeviceTables* T_dev, const GzAsmArgs& A, int pass, int64_t text_bytes, hipStream_t s);
 // small batches, one launch (gz_small.inc): G documents per workgroup, G <= GZ_SMALL_DOCS_PER_WG and every group of G

@@ -101,6 +101,8 @@ def load_library():
     L.gz_expand_rows.argtypes = [vp, vp, vp, i64, i32, vp, vp]
     L.gz_compact_rows16.argtypes = [vp, vp, vp, i64, i32, vp, P(i64)]
     L.gz_expand_rows16.argtypes = [vp, vp, vp, i64, i32, vp, vp]
+    L.gz_compact_block.argtypes = [vp, vp, vp, i64, i32, i32, vp, P(i64)]
+    L.gz_expand_block.argtypes = [vp, vp, i32, i64, i32, i64, vp, vp]
     L.gz_host_tables_create.argtypes = [vp, sz, vp, sz, P(C.c_char_p), P(vp)]
     L.gz_host_tables_destroy.argtypes = [vp]; L.gz_host_tables_destroy.restype = None
     L.gz_host_tables_array.argtypes = [vp, C.c_int, P(vp), P(i64)]
@@ -478,8 +480,9 @@ class Context:
                                               C.c_void_p(d_block), C.byref(total)))
         return total.value
 
-    def expand_block(self, d_block, n_rows, row_len, d_ids, d_mask, bits: int = 16):
-        self._check(self.lib.gz_expand_block(self.handle, C.c_void_p(d_block), bits, n_rows, row_len, C.c_void_p(d_ids), C.c_void_p(d_mask)))
+    def expand_block(self, d_block, n_rows, row_len, d_ids, d_mask, bits: int = 16, total: int = 0xFFFFFFFF):
+        """`total`: the entry count the block was announced with (block_total / compact_block on the sending side)."""
+        self._check(self.lib.gz_expand_block(self.handle, C.c_void_p(d_block), bits, n_rows, row_len, int(total), C.c_void_p(d_ids), C.c_void_p(d_mask)))
 
     def gather_rows(self, d_send, n_rows_local, row_len, d_recv, rows_per_rank, root=0):
         rpr = np.ascontiguousarray(rows_per_rank, dtype=np.int64)

@@ -13,11 +13,18 @@ except ImportError:                             # pragma: no cover
     _gz_pack = None
 
 
+PINNED_MIN_TEXTS = 20000        # smaller batches are packed into an ordinary buffer: the library stages those through its own pinned blocks
+
+
 def pack_pinned(texts: Sequence[str], holder, ctx):
     """`pack` straight into a page-locked arena `holder` keeps (holder._pin_text: grown when too small): no fresh buffer of the
     batch's size, no second copy, and the H2D copy that follows is real DMA.  Returns (uint8 view of the arena, int64 offsets).
-    Falls back to `pack` when the C packer is not built."""
-    if _gz_pack is None or not hasattr(_gz_pack, "pack_into") or len(texts) < 8:
+    Falls back to `pack` when the C packer is not built, and for batches of fewer than PINNED_MIN_TEXTS texts (no 16 MB of pinned
+    memory for a handful of sentences).
+
+    The returned text is a VIEW of the one arena the holder keeps: the next call on the same holder overwrites it.  Callers hold
+    `holder._batch_lock` from this call until the library has consumed the text (Tokenize.encode_batch / encode_to_device do)."""
+    if _gz_pack is None or not hasattr(_gz_pack, "pack_into") or len(texts) < PINNED_MIN_TEXTS:
         return pack(texts)
     off = np.empty(len(texts) + 1, dtype=np.int64)
     arena = getattr(holder, "_pin_text", None)

@@ -78,21 +78,31 @@ def block_words(n_rows: int, n_entries: int, bits: int) -> int:
 
 class GatherRound:
     """Root-side state of ONE exchange round (local shard j of every rank): where each peer's block starts in the
-    receive buffer, how large the buffer must be, and what every peer announced."""
+    receive buffer, how large the buffer must be, and what every peer announced.  A rank's block is
+    [n_real[rows] | first[rows] | entries] (`block_words`): `rows[q]` is the number of rows of rank q's shard of this round --
+    ranks need not own equally many."""
 
-    def __init__(self, world: int, bits: int, slack: float = 1.05, pad: int = 1024):
+    def __init__(self, world: int, bits: int, rows: Sequence[int], slack: float = 1.05, pad: int = 1024):
+        if len(rows) != world or any(int(r) < 0 for r in rows):
+            raise ValueError("%d row counts for %d ranks" % (len(rows), world))
         self.world, self.bits, self.slack, self.pad = world, bits, slack, pad
+        self.rows: List[int] = [int(r) for r in rows]
         self.capacity = 0                 # int32 words the receive buffer currently holds
         self.totals: List[int] = []       # entries announced by every rank
-        self.words: List[int] = []        # int32 words of every rank's block
+        self.words: List[int] = []        # int32 words of every rank's whole block (row lengths + row starts + entries)
+
+    def worst_case_words(self, row_len: int) -> int:
+        """int32 words of the round when every row of every rank is full: a receive buffer of this size never grows."""
+        return sum(block_words(n, n * int(row_len), self.bits) for n in self.rows)
 
     def announce(self, totals: Sequence[int]) -> int:
-        """Record what the ranks announced for this round; returns the capacity (in int32 words) the receive buffer must
-        have -- the current one when it is enough, else the grown one (the caller re-allocates when it differs)."""
+        """Record the ENTRY counts the ranks announced for this round; returns the capacity (in int32 words) the receive
+        buffer must have -- the current one when it is enough, else the grown one (the caller re-allocates when it
+        differs)."""
         if len(totals) != self.world:
             raise ValueError("%d totals for %d ranks" % (len(totals), self.world))
         self.totals = [int(t) for t in totals]
-        self.words = [csr_words(t, self.bits) for t in self.totals]
+        self.words = [block_words(n, t, self.bits) for n, t in zip(self.rows, self.totals)]
         need = sum(self.words)
         if need > self.capacity:
             return int(need * self.slack) + self.pad

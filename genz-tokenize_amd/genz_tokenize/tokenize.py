@@ -13,6 +13,7 @@ that returns numpy arrays, which is what the GPU is for.
 from __future__ import annotations
 
 import os
+import threading
 from typing import Dict, List, Optional, Sequence
 
 import numpy as np
@@ -52,6 +53,7 @@ class Tokenize(object):
         self.mask_token, self.unk_token = mask_token, unk_token
         if not hasattr(self, "_ctx"):
             self._ctx = _native.Context(device)
+            self._batch_lock = threading.Lock()      # the batch calls' pinned text arena (one per object): _packing.pack_pinned
         self._vocab_texts: List[str] = []
         self._bpe_text = ""
         self._dicts = {}
@@ -284,7 +286,7 @@ class Tokenize(object):
             raise ValueError("texts and pair_texts differ in length")
         if (pair_texts is None and padding and truncation and max_len is not None and int(max_len) >= 1 and len(texts) >= 20000
                 and _packing._gz_pack is not None and not return_offset):
-            return self._encode_batch_large(texts, int(max_len), word_table)
+            return self._shape(self._encode_batch_large(texts, int(max_len), word_table), len(texts))
         r = self._run(list(texts), None if pair_texts is None else list(pair_texts), max_len, padding, truncation,
                       word_table, keep_words=bool(return_offset))
         out = self._shape(r, len(texts))
@@ -334,39 +336,14 @@ class Tokenize(object):
         return [(int(a), int(b)) for a, b in result["offset"][lo:hi]]
 
     def _encode_batch_large(self, texts, max_len, word_table):
-        """Large dense single-text batches: the strings are packed on threads (csrc/gz_pack.c), the packed text goes through
-        the CSR host path (only the text and the rows' real entries cross PCIe, in a pinned arena this object keeps), and the
-        dense [N, max_len] arrays the caller gets are filled from the CSR rows by host threads -- the same values as the
-        dense device path, without 2 * N * max_len * 4 bytes of mostly padding crossing PCIe into pageable memory."""
+        """Large dense single-text batches: the strings are packed on threads (csrc/gz_pack.c) straight into a pinned arena this
+        object keeps, and the packed text goes through the library's dense host path (gz_encode_batch: sub-batches, only the text
+        and the rows' real entries cross PCIe, the [N, max_len] arrays are padded into place by host threads inside the call).
+        The arena is ONE buffer per object: the lock keeps a second thread's batch out of it until this call has consumed it."""
         self._sync_tables()
-        ctx = self._ctx
-        tb, to = _packing.pack_pinned(texts, self, ctx)               # (straight into the pinned text arena)
-        n = len(to) - 1
-        nbytes = int(to[-1]) if n else 0
-        sp = self._special_ids()
-        bits = 16 if self.vocab_size() <= 65536 and max(sp) < 65536 and min(sp) >= 0 else 32
-        arena = getattr(self, "_arena", None)
-        cap = max(min(n * max_len, nbytes + 2 * n), 1)
-        if arena is None or arena["tok"].size * arena["tok"].itemsize < cap * 4 or arena["nr"].size < n:
-            arena = dict(tok=ctx.pinned_empty(max(int(cap * 1.25), 1 << 18), np.int32), nr=ctx.pinned_empty(max(int(n * 1.25), 1024), np.int32))
-            self._arena = arena
-        flags = 0 if word_table else _native.GZ_NO_WORD_TABLE
-        tokbuf = arena["tok"].view(np.uint16)[:2 * arena["tok"].size] if bits == 16 else arena["tok"]
-        try:
-            tokens, n_real = ctx.encode_csr(tb, to, max_len, bits, flags, tokens=tokbuf, n_real=arena["nr"])
-        except _native.GzError as e:
-            if bits == 16 and e.code == _native.GZ_E_LIMIT:              # an id collision pushed an id past 65535
-                bits = 32
-                tokens, n_real = ctx.encode_csr(tb, to, max_len, 32, flags, tokens=arena["tok"], n_real=arena["nr"])
-            else:
-                raise
-        row_off = np.zeros(n + 1, dtype=np.int64)
-        np.cumsum(n_real, out=row_off[1:])
-        ids = np.empty((n, max_len), dtype=np.int32)
-        mask = np.empty((n, max_len), dtype=np.int32)
-        _packing._gz_pack.expand(tokens, bits, n_real, row_off, max_len, int(sp[0]), ids, mask)
-        return dict(input_ids=ids, attention_mask=mask, row_off=np.arange(n + 1, dtype=np.int64) * max_len, n_real=np.array(n_real[:n]),
-                    status=np.zeros(n, dtype=np.int32), dense=True, max_len=max_len)
+        with self._batch_lock:
+            tb, to = _packing.pack_pinned(texts, self, self._ctx)
+            return self._ctx.encode(tb, to, None, None, max_len, True, True, 0 if word_table else _native.GZ_NO_WORD_TABLE)
 
     def encode_packed(self, text_u8: np.ndarray, offsets: np.ndarray, pair_u8=None, pair_offsets=None,
                       max_len: Optional[int] = None, padding: bool = True, truncation: bool = True,
@@ -418,7 +395,12 @@ class Tokenize(object):
         if max_len is None or int(max_len) < 1:
             raise ValueError("encode_to_device needs max_len >= 1 (dense rows)")
         self._sync_tables()
-        ctx, L = self._ctx, int(max_len)
+        with self._batch_lock:                                         # (the pinned text arena is one buffer per object: see pack_pinned)
+            return self._encode_to_device_locked(texts, pair_texts, int(max_len))
+
+    def _encode_to_device_locked(self, texts, pair_texts, L):
+        from .handoff import DeviceArray
+        ctx = self._ctx
         t, to = _packing.pack_pinned(texts, self, ctx)                 # (a pinned arena this object keeps: the H2D copy is real DMA)
         n = len(to) - 1
         pair = pair_texts is not None

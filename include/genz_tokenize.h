@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define GZ_VERSION 0x010000
+#define GZ_VERSION 0x010100   /* 1.1: gz_expand_block takes the block's entry total (the block layout itself is round 5's) */
 
 #define GZ_OK            0
 #define GZ_E_INVALID    -1   /* bad argument */
@@ -236,7 +236,12 @@ int64_t gz_limit(int which);
  *   hot_wgs, hot_miss_wgs (0..65536; 0)   grids of the word / merge kernels (0: as many workgroups as the chip holds)
  *   m2_split_min (>= 0; 65536), m2_split_always (0..1; 0)   when the merge kernel's two instances share a launch
  *   builder: tab_slack (2..64; 16), ph_force_overflow (>= 0; 0), ph_hot_slots (0..8192; 1024), word_weights (0..2; 0)
- *   diagnostic build only: diag_poison (0..1), rows_dpw, rows_dbg, ablate
+ *   host_threads (0..256; 0)   worker threads of a large host call (0: by the processors this process may use, at most 32)
+ *   dense_csr (0..1; 1)        a large dense single-text gz_encode_batch brings only the rows' real entries over the bus and pads them
+ *                              into the caller's arrays on the host; 0: the dense rows cross
+ *   inject_bad_alloc (>= 0; 0) test hook: the k-th allocation site reached from now on throws std::bad_alloc (the call answers GZ_E_NOMEM)
+ *   diagnostic build only: diag_poison (0..1), rows_dpw, rows_dbg, ablate, diag_guard (0..2: every device buffer its own mapping
+ *                              between unmapped granules, no slack -- 1 the buffer ends at its mapping's last byte, 2 it starts at the first)
  * Returns GZ_OK, or GZ_E_INVALID for an unknown key or a value out of range (nothing is changed then). */
 int  gz_debug_set(gz_ctx *ctx, const char *key, int64_t value);
 
@@ -338,7 +343,10 @@ int  gz_expand_rows16(gz_ctx *ctx, const uint16_t *compact_dev, const int32_t *n
  *     block_dev = [ int32 n_real[n_rows] | uint32 first[n_rows] | the rows' real entries, `bits` (16 | 32) bits each ]
  * row r's entries are the n_real[r] ones from entry first[r] on (round 4: no `first` -- the receiver scanned n_real again).
  * gz_compact_block writes it from dense rows (total_host receives the number of entries; the block is 2 n_rows + ceil(total * bits /
- * 32) int32 words long), gz_expand_block is the inverse on the receiving side.
+ * 32) int32 words long), gz_expand_block is the inverse on the receiving side: `total_entries` is the entry count the block was
+ * announced with (what gz_block_total / gz_compact_block returned on the sending side).  A block comes from another process: a row
+ * that claims more than row_len entries, or entries beyond total_entries -- a truncated block, one written in another layout -- is
+ * written as padding only, never followed, and the next gz_sync answers GZ_E_INVALID.
  * gz_encode_emit_block arms the NEXT encode call (a dense one: GZ_E_INVALID from that call otherwise) to leave its block in block_dev
  * (2 n_docs + ceil(n_docs * max_len * bits / 32) words at most) as part of the call itself: the scan of the row lengths and the
  * compact kernel run right behind the call's kernels on the call's own stream (beside the NEXT call's kernels, on the exchange
@@ -349,7 +357,7 @@ int  gz_encode_emit_block(gz_ctx *ctx, int32_t *block_dev, int32_t bits);
 int  gz_block_total(gz_ctx *ctx, int32_t back, int64_t *total_host);
 int  gz_compact_block(gz_ctx *ctx, const int32_t *rows_dev, const int32_t *n_real_dev, int64_t n_rows, int32_t row_len,
                       int32_t bits, int32_t *block_dev, int64_t *total_host);
-int  gz_expand_block(gz_ctx *ctx, const int32_t *block_dev, int32_t bits, int64_t n_rows, int32_t row_len,
+int  gz_expand_block(gz_ctx *ctx, const int32_t *block_dev, int32_t bits, int64_t n_rows, int32_t row_len, int64_t total_entries,
                      int32_t *ids_dev, int32_t *mask_dev);
 
 #ifdef __cplusplus

@@ -30,11 +30,31 @@ def pytest_configure(config):
     # kept whatever the runtime had said -- see _gpu_tests_write_to_the_real_stderr below.)
     os.environ.setdefault("AMD_LOG_LEVEL", "1")
     os.environ.setdefault("LIBC_FATAL_STDERR_", "1")
+    _install_sigtrace()
     # switches of the library a parent test asked for (GZ_TEST_SWITCHES="small=0,scan_multi=0": gz_switches.py -> gz_debug_set): set
     # as process-wide defaults before any context exists.  The library itself reads no switch from the environment.
     if os.environ.get("GZ_TEST_SWITCHES"):
         import gz_switches
         gz_switches.apply()
+
+
+SIGTRACE = os.path.join(ROOT, "tests", "native", "sigtrace.so")
+
+
+def _install_sigtrace():
+    """tests/native/sigtrace.c: native frames on stderr when the process dies of SIGABRT / SIGSEGV -- the faulthandler's Python stack
+    ends at the ctypes call and cannot say whether the HSA runtime (a GPU memory fault), glibc or std::terminate raised.  Built here
+    (gcc, a second), loaded into this process, and named in GZ_SIGTRACE so that `_run_child` preloads it into every child."""
+    src = os.path.join(ROOT, "tests", "native", "sigtrace.c")
+    try:
+        if not os.path.exists(SIGTRACE) or os.path.getmtime(SIGTRACE) < os.path.getmtime(src):
+            import subprocess
+            subprocess.run(["gcc", "-O1", "-g", "-shared", "-fPIC", "-o", SIGTRACE, src], check=True, capture_output=True)
+        import ctypes
+        ctypes.CDLL(SIGTRACE, mode=ctypes.RTLD_GLOBAL)
+        os.environ["GZ_SIGTRACE"] = SIGTRACE
+    except Exception as e:  # noqa: BLE001 -- diagnostics must never cost a test run
+        sys.stderr.write("[conftest] sigtrace not installed: %s\n" % e)
 
 
 def read_jsonl(name):

@@ -104,7 +104,11 @@ def test_shard_ownership_and_root_bookkeeping():
     rng = np.random.default_rng(3)
     for world in (2, 4, 8):
         for bits in (16, 32):
-            plan = GatherRound(world, bits)
+            # ranks need not own equally many rows: a block is [n_real[rows] | first[rows] | entries], and where a peer's block
+            # starts in the receive buffer depends on the rows of every rank before it
+            rows = [int(x) for x in rng.integers(0, 3_000, size=world)]
+            plan = GatherRound(world, bits, rows)
+            assert plan.worst_case_words(64) == sum(block_words(n, n * 64, bits) for n in rows)
             cap_seen = 0
             for _ in range(5):                                   # several steps: the buffer only ever grows
                 totals = [int(x) for x in rng.integers(0, 50_000, size=world)]
@@ -113,10 +117,19 @@ def test_shard_ownership_and_root_bookkeeping():
                 if cap != plan.capacity:
                     plan.capacity = cap                          # (the caller re-allocates)
                 cap_seen = plan.capacity
-                assert plan.words == [csr_words(t, bits) for t in totals]
+                assert plan.words == [2 * n + csr_words(t, bits) for n, t in zip(rows, totals)]
                 offs = [plan.word_offset(q) for q in range(world)]
                 assert offs[0] == 0 and all(offs[q + 1] - offs[q] == plan.words[q] for q in range(world - 1))
                 assert offs[-1] + plan.words[-1] <= plan.capacity
+                # a receive buffer laid out by the plan, read back peer by peer: each block's header is its own rows' lengths
+                buf = np.full(plan.capacity, -7, dtype=np.int64)
+                for q in range(world):
+                    buf[plan.word_offset(q):plan.word_offset(q) + rows[q]] = q          # (the n_real part of rank q's block)
+                for q in range(world):
+                    o = plan.word_offset(q)
+                    assert (buf[o:o + rows[q]] == q).all() and (rows[q] == 0 or buf[o + rows[q]] == -7)
+            with pytest.raises(ValueError):
+                GatherRound(world, bits, rows[:-1])
             with pytest.raises(ValueError):
                 plan.announce([1] * (world + 1))
 

@@ -42,6 +42,8 @@ def _run_child(cmd, name, env=None, timeout=600, cwd=None):
     env = dict(os.environ if env is None else env)
     env.setdefault("PYTHONFAULTHANDLER", "1")
     env.setdefault("AMD_LOG_LEVEL", "1")
+    if env.get("GZ_SIGTRACE") and os.path.exists(env["GZ_SIGTRACE"]) and not env.get("LD_PRELOAD"):
+        env["LD_PRELOAD"] = env["GZ_SIGTRACE"]                    # native frames when the child dies of a signal (tests/native/sigtrace.c)
     if cmd and cmd[0] == sys.executable and "-X" not in cmd[:3]:
         cmd = [cmd[0], "-X", "faulthandler"] + list(cmd[1:])
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -1058,9 +1060,22 @@ def test_compact_block_round_trip(tok):
         assert total == int(nr.sum())
         head = np.empty(n, dtype=np.int32); ctx.sync(); ctx.d2h(head, d_blk)
         assert np.array_equal(head, nr)
-        ctx.expand_block(d_blk, n, L, d_i2, d_m2, bits=bits); ctx.sync()
+        ctx.expand_block(d_blk, n, L, d_i2, d_m2, bits=bits, total=total); ctx.sync()
         i2 = np.empty_like(ids); m2 = np.empty_like(ids); ctx.d2h(i2, d_i2); ctx.d2h(m2, d_m2)
         assert np.array_equal(i2, ids) and np.array_equal(m2, r["attention_mask"])
+        # a block announced with FEWER entries than its rows claim (truncated on the way, or written in another layout): the rows that
+        # do not fit are written as padding, nothing beyond the announced entries is read, and the next synchronisation says so
+        if total > 10:
+            ctx.expand_block(d_blk, n, L, d_i2, d_m2, bits=bits, total=total // 2)
+            with pytest.raises(__import__("genz_tokenize")._native.GzError) as ei:
+                ctx.sync()
+            assert "exchange block" in str(ei.value)
+            ctx.d2h(i2, d_i2)
+            first = np.zeros(n + 1, dtype=np.int64); np.cumsum(nr, out=first[1:])
+            fits = first[1:] <= total // 2
+            assert fits.any() and not fits.all()
+            assert np.array_equal(i2[fits], ids[fits]) and (i2[~fits] == tok._special_ids()[0]).all()
+            ctx.sync()                                                 # (reported once, then cleared)
         for q in (d_blk, d_i2, d_m2):
             ctx.free(q)
     ctx.free(d_ids); ctx.free(d_nr)
@@ -1097,7 +1112,7 @@ def test_encode_emits_its_exchange_block(tok, sampler, case):
             assert ctx.block_total(2 - k) == int(nr.sum())
             ctx.exchange_select(2 - k)
             d_i2, d_m2 = ctx.alloc(4 * n * L), ctx.alloc(4 * n * L)
-            ctx.expand_block(blocks[k], n, L, d_i2, d_m2, bits=bits); ctx.sync()
+            ctx.expand_block(blocks[k], n, L, d_i2, d_m2, bits=bits, total=int(nr.sum())); ctx.sync()
             i2 = np.empty((n, L), np.int32); m2 = np.empty((n, L), np.int32); head = np.empty(n, np.int32)
             ctx.d2h(i2, d_i2); ctx.d2h(m2, d_m2); ctx.d2h(head, blocks[k])
             assert np.array_equal(head, nr) and np.array_equal(i2, ids) and np.array_equal(m2, mask)
@@ -1117,9 +1132,61 @@ def test_encode_emits_its_exchange_block(tok, sampler, case):
     ctx.encode_device(d_t, d_o, 0, 0, n, L, flags, n * L, outs[0][0], outs[0][1], d_n_real=outs[0][5], h_text_off=oa); ctx.sync()
     with pytest.raises(_native.GzError):
         ctx.block_total(0)
+    # the arming belongs to the next DEVICE call only: host calls in between (dense and ragged) and a table reload neither consume
+    # it nor fail on it, nor write into the block (sized for another call)
+    if case == "rows1":
+        ctx.encode_emit_block(blk, 32)
+        few = 50
+        h = tok.encode_packed(ta[:oa[few]], oa[:few + 1], max_len=L)                       # dense host call
+        assert np.array_equal(h["input_ids"], ids[:few])
+        h = tok.encode_packed(ta[:oa[few]], oa[:few + 1])                                  # ragged host call: no "needs a dense call"
+        assert int(h["row_off"][-1]) >= few * 2
+        data = os.path.join(os.path.dirname(_native.__file__), "data")
+        ctx.load_tables(open(os.path.join(data, "vocab.txt"), "rb").read(), open(os.path.join(data, "bpe.codes"), "rb").read(),
+                        [tok.pad_token, tok.bos_token, tok.eos_token, tok.mask_token, tok.unk_token])   # (encodes every candidate word through the same function)
+        ctx.encode_device(d_t, d_o, 0, 0, n, L, flags, n * L, outs[0][0], outs[0][1], d_n_real=outs[0][5], h_text_off=oa)
+        assert ctx.block_total(0) == int(nr.sum())                  # the device call still had its arming
+        d_i2, d_m2 = ctx.alloc(4 * n * L), ctx.alloc(4 * n * L)
+        ctx.expand_block(blk, n, L, d_i2, d_m2, bits=32, total=int(nr.sum())); ctx.sync()
+        i2 = np.empty((n, L), np.int32); ctx.d2h(i2, d_i2)
+        assert np.array_equal(i2, ids)
+        ctx.free(d_i2); ctx.free(d_m2)
     ctx.free(blk)
     for q in [d_t, d_o] + [x for o in outs for x in o]:
         ctx.free(q)
+
+
+def test_allocation_failure_inside_an_entry_point_is_an_error_code(tok, sampler):
+    """No C++ exception crosses the C ABI: every extern "C" body is a function-try-block.  The switch inject_bad_alloc makes the
+    k-th allocation site (where an entry point grows a std::vector) throw std::bad_alloc: the call must answer GZ_E_NOMEM -- not
+    std::terminate, which is a silent SIGABRT -- and the context must work afterwards."""
+    from genz_tokenize import _native
+    ctx = tok._ctx
+    n, L = 30000, 32
+    ta, oa, _ = corpus.config_corpus(3, n_docs=n, seed=5, sampler=sampler)
+    ta = np.ascontiguousarray(ta); oa = np.ascontiguousarray(oa, dtype=np.int64)
+    want = tok.encode_packed(ta, oa, max_len=L)
+    calls = {
+        "dense host call (sub-batches, rows padded on host threads)": lambda: tok.encode_packed(ta, oa, max_len=L),
+        "dense host call, rows over the bus": lambda: tok.encode_packed(ta, oa, ta, oa, max_len=L),
+        "csr host call": lambda: tok.encode_packed_csr(ta, oa, max_len=L),
+        "word counts": lambda: tok.encode_batch(["a b c", "d"] * 300, return_offset=True),
+        "table digest": lambda: ctx.table_digest(),
+    }
+    for what, call in calls.items():
+        hit = 0
+        for k in range(1, 8):
+            _native.debug_set("inject_bad_alloc", k, ctx)
+            try:
+                call()
+            except _native.GzError as e:
+                assert e.code == _native.GZ_E_NOMEM, (what, k, str(e))
+                hit += 1
+            finally:
+                _native.debug_set("inject_bad_alloc", 0, ctx)
+        assert hit >= 1, what                                         # (at least the first site of every call is reached)
+        r = tok.encode_packed(ta, oa, max_len=L)                      # ... and the context is whole afterwards
+        assert np.array_equal(r["input_ids"], want["input_ids"]) and np.array_equal(r["n_real"], want["n_real"])
 
 
 def test_gather_rows_refuses_bad_arguments_before_opening_a_group(tok):

@@ -216,3 +216,23 @@ def test_host_builder_threads_under_tsan(tmp_path):
                        env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1:exitcode=66"))
     assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-4000:]
     assert "tsan driver ok" in r.stdout and "ThreadSanitizer" not in r.stderr
+
+
+def test_allocation_failure_in_the_host_builder_is_an_error_code(tmp_path):
+    """No C++ exception crosses the C ABI.  tests/native/alloc_fail_main.cpp links the host-only entry points with an operator new
+    that throws std::bad_alloc at the k-th allocation and sweeps k over a build of the bundled tables (the first 400 allocations one
+    by one, then every 997th of the ~50 000): every failure point -- on the calling thread or on the builder's helper threads -- must
+    come back as GZ_E_NOMEM with no tables, never as std::terminate (a silent SIGABRT, rc -6 here).  The GPU-side entry points have the
+    same barrier (function-try-blocks, gz_api.cpp) and their own injection test in tests/test_gpu_parity.py."""
+    import os
+    import subprocess
+    from conftest import ROOT, DATA
+    csrc = os.path.join(ROOT, "genz-tokenize_amd", "csrc")
+    exe = str(tmp_path / "alloc_fail")
+    c = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-DGZ_HOST_ONLY", os.path.join(ROOT, "tests", "native", "alloc_fail_main.cpp"),
+                        os.path.join(csrc, "gz_tables.cpp"), os.path.join(csrc, "gz_host_api.cpp"), "-o", exe, "-lpthread"],
+                       capture_output=True, text=True, timeout=600)
+    assert c.returncode == 0, c.stderr[-3000:]
+    r = subprocess.run([exe, os.path.join(DATA, "vocab.txt"), os.path.join(DATA, "bpe.codes"), "997"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, "rc %d\n%s\n%s" % (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
+    assert "other: 0" in r.stdout and "GZ_E_NOMEM" in r.stdout
