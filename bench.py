@@ -155,6 +155,28 @@ def _oracle_slice(job):
 _CPU_WORK = None
 
 
+def cpu_baseline_small(budget_s=4.0):
+    """the same loop on cfg 2 = BASELINE configs[1] (10 000 short sentences, max_len 128) -- the whole corpus when the
+    budget allows (it takes the port ~ 0.6 s), one thread, one call per document."""
+    global _CPU_WORK
+    import corpus
+    t2, o2, L2 = corpus.config_corpus(2)
+    keep = _CPU_WORK
+    _CPU_WORK = (np.ascontiguousarray(t2), np.ascontiguousarray(o2, dtype=np.int64), L2)
+    n = len(o2) - 1
+    nb, ntok, dt = _oracle_slice((0, n, budget_s))
+    _CPU_WORK = keep
+    ratio = None
+    try:
+        ratio = json.load(open(os.path.join(ROOT, "tests", "golden", "calibration.json"))).get("port_over_reference")
+    except Exception:  # noqa: BLE001
+        pass
+    return {"value": round(nb / dt / 1e6, 4), "unit": "MB/s", "cores": 1, "kind": "port", "tokens_per_s": round(ntok / dt, 1),
+            "sample": "%.2f of the %.2f MB of BASELINE configs[1] (%d sentences, max_len=%d), oracle/gz_oracle.py, %.2f s, one thread, one call per "
+                      "document" % (nb / 1e6, int(o2[-1]) / 1e6, n, L2, dt),
+            "reference_equivalent_MB_per_s": round(nb / dt / 1e6 / ratio, 4) if ratio else None}
+
+
 def cpu_baseline(text, offs, max_len, budget_s=10.0):
     """The oracle (a from-scratch restatement of the reference's Python loop; kind "port") on a bounded prefix of the
     roofline workload (BASELINE configs[2]): one thread, one call per document -- like the reference -- and, as the
@@ -311,6 +333,10 @@ def main():
         cfg2 = (np.ascontiguousarray(t2_), np.ascontiguousarray(o2_, dtype=np.int64), L2_)
         if not args.no_cpu_baseline:
             cpu["cpu_baseline"] = cpu_baseline(*cfg2)
+            try:
+                cpu["cpu_baseline_configs_1"] = cpu_baseline_small()
+            except Exception as e:  # noqa: BLE001 -- a secondary figure must not cost the bench line
+                cpu["cpu_baseline_configs_1"] = {"error": str(e)}
             try:
                 cpu["cpu_baseline_c"] = cpu_baseline_c(*cfg2)
             except Exception as e:  # noqa: BLE001 -- a secondary figure must not cost the bench line
@@ -606,6 +632,8 @@ def main():
         sec = {"headline_host_paths": headline_e2e(ctx, shards, L, int(total_tokens))}
         sec.update(secondary(ctx, tok, flags, args, cfg2))
         sec.update(cpu)
+        if "cpu_baseline_configs_1" in sec and "configs_1_small_batch" in sec:       # (the CPU figure beside its workload)
+            sec["configs_1_small_batch"]["cpu_baseline"] = sec.pop("cpu_baseline_configs_1")
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -777,11 +805,15 @@ def secondary(ctx, tok, flags, args, cfg2):
     # (iii) Python end-to-end: list of str in (packing included), numpy arrays out
     raw = text.tobytes()
     docs = [raw[offs[i]:offs[i + 1]].decode("utf-8") for i in range(R.n)]
-    t_a = time.perf_counter()
-    r = tok.encode_batch(docs, max_len=L)
-    py_e2e = time.perf_counter() - t_a
-    ok_py = int(r["attention_mask"].sum(dtype=np.int64)) == n_tok
-    del r
+    py_runs = []
+    ok_py = True
+    for _ in range(2):                       # (the first call also allocates the object's pinned text arena: both runs are in the line, the better one counts --
+        t_a = time.perf_counter()            #  as for every other timing here)
+        r = tok.encode_batch(docs, max_len=L)
+        py_runs.append(time.perf_counter() - t_a)
+        ok_py = ok_py and int(r["attention_mask"].sum(dtype=np.int64)) == n_tok
+        del r
+    py_e2e = min(py_runs)
     # (iii') the path a model-feed user takes: list of str in, dense [N, L] rows LEFT IN HBM (DLPack hand-off): packing + H2D of the text +
     # kernels; only n_real [N] comes back
     py_dev = []
@@ -795,7 +827,7 @@ def secondary(ctx, tok, flags, args, cfg2):
     out["configs_2_roofline_run"] = {
         "workload": "BASELINE configs[2]: %d mixed-length sentences (%.1f MB), max_len=%d, one launch of the pipeline" % (R.n, R.in_bytes / 1e6, L),
         "verified": "reference sha256 (tests/golden/g5_hashes.json cfg3_1M, computed by the reference itself): match",
-        "timings": {"kernels_ms": round(k_ms, 4), "device_e2e_ms": round(min(e2e) * 1e3, 3), "python_e2e_ms": round(py_e2e * 1e3, 2),
+        "timings": {"kernels_ms": round(k_ms, 4), "device_e2e_ms": round(min(e2e) * 1e3, 3), "python_e2e_ms": round(py_e2e * 1e3, 2), "python_e2e_ms_runs": [round(x * 1e3, 2) for x in py_runs],
                     "python_to_device_ms": round(min(py_dev) * 1e3, 2),
                     "device_e2e_dense_pageable_ms": round(min(e2e_dense) * 1e3, 2), "device_e2e_bytes_over_pcie": int(R.in_bytes + 8 * (R.n + 1) + csr_bytes),
                     "MB_per_s": {"kernels": round(R.in_bytes / k_ms / 1e3, 1), "device_e2e": round(R.in_bytes / min(e2e) / 1e6, 1), "device_e2e_dense_pageable": round(R.in_bytes / min(e2e_dense) / 1e6, 1),

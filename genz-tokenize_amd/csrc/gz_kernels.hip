@@ -45,6 +45,20 @@ __device__ __noinline__ bool gz_chk_fail(unsigned code, unsigned long long v, un
 #define GZ_CHK(code, v, bound) true
 #endif
 
+// In-kernel stamps (diagnostic builds only, -DGZ_DIAG: tools/ab_diag.sh): cycles per phase, summed over waves
+#ifdef GZ_DIAG
+__device__ unsigned long long gz_prof[64];
+#define PROF_DECL unsigned long long prof_t0 = __builtin_readcyclecounter(), prof_acc[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}
+#define PROF(i) do { const unsigned long long t_ = __builtin_readcyclecounter(); prof_acc[i] += t_ - prof_t0; prof_t0 = t_; } while (0)
+#define PROF_CNT(i, v) do { prof_acc[i] += (unsigned long long)(v); } while (0)
+#define PROF_FLUSH(base) do { if (lane_id() == 0) for (int i_ = 0; i_ < 12; ++i_) atomicAdd(&gz_prof[(base) + i_], prof_acc[i_]); } while (0)
+#else
+#define PROF_DECL
+#define PROF(i)
+#define PROF_CNT(i, v)
+#define PROF_FLUSH(base)
+#endif
+
 // streaming (write-once) 16-byte store that does not displace the tables from L2
 __device__ __forceinline__ void nt_store4(int32_t* p, int32_t a, int32_t b, int32_t c, int32_t d)
 {

@@ -30,4 +30,4 @@ for it in range(iters):
     ctx.encode_device(d_text, d_off, 0, 0, n, L, flags, n * L, d_ids, d_mask, d_n_real=d_nreal)
     ctx.sync()
     lib.gz_diag_prof(buf, 0)
-    print("iter", it, "kernel ms %.3f" % ctx.timing()[0], "prof", [int(x) for x in buf[:12]], "pre", [int(x) for x in buf[12:24]])
+    print("iter", it, "kernel ms %.3f" % ctx.timing()[0], "prof", [int(x) for x in buf[:12]], "pre", [int(x) for x in buf[12:24]], "rows1", [int(x) for x in buf[24:36]])
