@@ -172,6 +172,7 @@ struct gz_ctx {
     int cache_status = 0;                // of the last gz_load_tables: 0 no cache, 1 hit, 2 miss (written), 3 a file was refused (rebuilt, rewritten), 4 rebuilt but not written
     bool building_words = false;         // the whole-word table is being built: ignore diagnostics
     GzOptions opt;                       // test / experiment switches (gz_debug_set): a copy of the process-wide defaults at creation
+    int n_fresh = 0;                     // diagnostic build: running number of this context's device allocations (switch diag_fresh_only)
 };
 
 namespace {
@@ -217,7 +218,7 @@ void alloc_site(gz_ctx* c)
 // mapped, which with hipMalloc they almost always are (it carves buffers out of large blocks): such an overrun faults only on the
 // day the allocator's layout puts an unmapped page there.  Here every workspace / table buffer is its OWN virtual-memory mapping
 // with an unmapped granule on both sides and NO slack: diag_guard = 1 puts the buffer's END on the last byte of its mapping
-// (16-byte aligned start), = 2 its START on the first byte.  One byte too far faults on the spot, every time, and the runtime's
+// (16-byte aligned start), = 2 its START on the first byte (the granule is 4 KiB on this runtime).  One byte too far faults on the spot, every time, and the runtime's
 // fault message (AMD_LOG_LEVEL=1 names the kernel) replaces a coin toss.
 struct GuardMap { void* base; size_t reserved; void* map_at; size_t mapped; hipMemGenericAllocationHandle_t h; };
 std::mutex g_guard_mu;
@@ -265,7 +266,11 @@ bool guard_free(void* user)
     hipDeviceSynchronize();
     hipMemUnmap(g.map_at, g.mapped);
     hipMemRelease(g.h);
-    hipMemAddressFree(g.base, g.reserved);
+    // The address range is NOT given back (hipMemAddressFree): a freed buffer's addresses are never handed out again.  Measured on
+    // this runtime (ROCm 7.2, gfx950; profiles/r06_ab_variants.txt series 0): a range that is reserved again right after it was
+    // freed gets the old addresses, and the first copy / kernel into the new mapping can still go through the old translation --
+    // rows came out wrong (no fault) in exactly the calls that re-allocated a buffer, and only with this allocator.  Address space
+    // is free; a stale pointer into a freed buffer now also faults for good.
     return true;
 }
 void dev_free(void* p) { if (p && !guard_free(p)) hipFree(p); }
@@ -275,8 +280,26 @@ void dev_free(void* p) { if (p) hipFree(p); }
 
 // zero_new: a fresh allocation is cleared before anything uses it (the chained-scan words are validated by a per-context
 // call number only: memory another context freed could otherwise carry words that look current)
-int ensure(gz_ctx* c, DBuf& b, size_t bytes, bool zero_new = false)
+#ifdef GZ_DIAG
+// diagnostic build, switch diag_fresh: a fresh allocation is filled with a byte of the tester's choice (fresh memory is usually
+// zero -- with hipMalloc; not with the guard allocator's mappings -- and zero hides a read of a word nobody wrote)
+int fresh_fill(gz_ctx* c, void* p, size_t bytes, const char* what)
 {
+    const int k = c->n_fresh++;
+    if (c->opt.diag_fresh <= 0 || (c->opt.diag_fresh_only >= 0 && c->opt.diag_fresh_only != k)) return GZ_OK;
+    if (c->opt.diag_fresh_only >= 0) fprintf(stderr, "[diag_fresh] allocation %d: %s, %zu bytes, filled with 0x%02X\n", k, what, bytes, c->opt.diag_fresh - 1);
+    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, hipMemset(p, c->opt.diag_fresh - 1, bytes));
+    HIPCHK(c, hipDeviceSynchronize());
+    return GZ_OK;
+}
+#define ensure(c, b, ...) ensure_named((c), (b), #b, __VA_ARGS__)
+#else
+#define ensure(c, b, ...) ensure_named((c), (b), nullptr, __VA_ARGS__)
+#endif
+int ensure_named(gz_ctx* c, DBuf& b, const char* what, size_t bytes, bool zero_new = false)
+{
+    (void)what;
     if (bytes <= b.cap && b.p) return GZ_OK;
     if (b.p) { dev_free(b.p); b.p = nullptr; b.cap = 0; }
 #ifdef GZ_DIAG
@@ -286,16 +309,23 @@ int ensure(gz_ctx* c, DBuf& b, size_t bytes, bool zero_new = false)
         int rc = guard_alloc(c, &b.p, want, c->opt.diag_guard);
         if (rc) { b.p = nullptr; return rc; }
         b.cap = want;
-        if (zero_new && hipMemset(b.p, 0, want) != hipSuccess) return fail(c, GZ_E_HIP, "hipMemset of a new workspace buffer failed");
+        if (zero_new) { if (hipMemset(b.p, 0, want) != hipSuccess) return fail(c, GZ_E_HIP, "hipMemset of a new workspace buffer failed"); }
+        else if ((rc = fresh_fill(c, b.p, want, what))) return rc;
         return GZ_OK;
     }
 #endif
     size_t want = bytes + 256;                      // slack: tile loads may touch up to 15 bytes past the text
     want = (want + 4095) & ~(size_t)4095;
+#ifdef GZ_DIAG
+    if (c->opt.diag_exact) want = ((bytes ? bytes : 16) + 15) & ~(size_t)15;
+#endif
     hipError_t e = hipMalloc(&b.p, want);
     if (e != hipSuccess) { b.p = nullptr; return fail(c, GZ_E_NOMEM, "hipMalloc(%zu): %s", want, hipGetErrorString(e)); }
     b.cap = want;
-    if (zero_new && hipMemset(b.p, 0, want) != hipSuccess) return fail(c, GZ_E_HIP, "hipMemset of a new workspace buffer failed");
+    if (zero_new) { if (hipMemset(b.p, 0, want) != hipSuccess) return fail(c, GZ_E_HIP, "hipMemset of a new workspace buffer failed"); }
+#ifdef GZ_DIAG
+    else { int rc = fresh_fill(c, b.p, want, what); if (rc) return rc; }
+#endif
     return GZ_OK;
 }
 
@@ -556,7 +586,7 @@ bool ids_fit_16(gz_ctx* c)
 
 int use_words_flags(gz_ctx* c, uint32_t flags)
 {
-#ifdef GZ_DIAG
+#if defined(GZ_DIAG) || defined(GZ_ABLATE)
     const int ablate = c->building_words ? 0 : c->opt.ablate;       // timing diagnostics only (diagnostic builds): results are wrong when set
 #else
     const int ablate = 0;
@@ -1330,8 +1360,8 @@ static int csr_core(gz_ctx* c, const uint8_t* text, const int64_t* text_off, int
     if ((rc = need_side_streams(c, false))) return rc;
 
     // which of the caller's buffers are pinned (gz_host_alloc): those are copied directly
-    const bool text_direct = tb >= 65536 && is_pinned(text);
-    const bool out_direct = !dense_out && is_pinned(O.n_real) && (O.capacity == 0 || is_pinned(O.tokens));
+    const bool text_direct = tb >= 65536 && is_pinned(text + text_off[0], (size_t)tb);
+    const bool out_direct = !dense_out && is_pinned(O.n_real, (size_t)n_docs * 4) && (O.capacity == 0 || is_pinned(O.tokens, (size_t)O.capacity * esz));
     if (!text_direct)
         for (int q = 0; q < (nsub > 1 ? 2 : 1); ++q)
             if ((rc = pinned_need(c, c->h_tin[q], c->h_tin_cap[q], (size_t)bmax + 16))) return rc;
@@ -1659,6 +1689,7 @@ try {
     HIPCHK(c, hipSetDevice(c->device));
     hipError_t e = hipHostMalloc(ptr, bytes ? bytes : 1, hipHostMallocDefault);
     if (e != hipSuccess) { *ptr = nullptr; return fail(c, GZ_E_NOMEM, "hipHostMalloc(%zu): %s", bytes, hipGetErrorString(e)); }
+    pinned_registry().add(*ptr, bytes ? bytes : 1);             // (the host paths copy to / from such blocks directly: gz_hostpath.h)
     return GZ_OK;
 } GZ_CATCH(c)
 
@@ -1667,6 +1698,7 @@ try {
     // Independent of the context's state on purpose: a pinned block may outlive the context that allocated it (a numpy
     // array finalized after Tokenize.close(), or at interpreter exit), so nothing of *c is touched; c may be NULL.
     (void)c;
+    if (ptr) pinned_registry().remove(ptr);
     if (ptr && hipHostFree(ptr) != hipSuccess) return GZ_E_HIP;
     return GZ_OK;
 } GZ_CATCH(c)

@@ -78,10 +78,16 @@ struct GzOptions {
     // ---- the host paths (gz_api.cpp)
     int32_t host_threads = 0;         // threads that move a large host call's rows into the caller's arrays (0: by the host's processors, at most 16)
     int32_t dense_csr = 1;            // 1: a large dense single-text host call brings only the rows' real entries over the bus and pads them on the host; 0: the dense rows cross
-    int32_t host_hints = 3;           // fresh output arrays of a large host call: bit 0 MADV_HUGEPAGE on them, bit 1 MADV_POPULATE_WRITE per piece before it is written
+    int32_t host_hints = 0;           // fresh output arrays of a large host call: bit 0 MADV_HUGEPAGE on them, bit 1 MADV_POPULATE_WRITE per piece before it is written
+                                      // (0: neither -- on the GPU box 16 threads fill 2 GB of fresh numpy arrays in 27 ms without them, 29-31 ms with)
     int32_t inject_bad_alloc = 0;     // test hook: k > 0 makes the k-th allocation site reached from now on throw std::bad_alloc (counts down to 0)
     // ---- diagnostic build only (results are WRONG with ablate / rows_dbg)
     int32_t diag_poison = 0, rows_dpw = 0, rows_dbg = 0, ablate = 0;
+    int32_t diag_fresh = 0;           // v > 0: every FRESH device allocation is filled with byte v - 1 before it is used (fresh memory is usually zero:
+                                      // a kernel that reads a word nobody wrote then reads garbage every time, not on the day the memory is reused)
+    int32_t diag_fresh_only = -1;     // >= 0: ... only the allocation with this running number (of the context), and its name goes to stderr
+    int32_t diag_exact = 0;           // 1: hipMalloc of exactly the bytes asked for (16-byte rounded), no slack, no 4-KiB rounding: buffers are re-allocated
+                                      // as often as with the guard allocator, in ordinary memory
     int32_t diag_guard = 0;           // device buffers from a guard-granule allocator: 1 the buffer ENDS at the last byte of its mapping (an unmapped granule behind it),
                                       // 2 it STARTS at the first byte (an unmapped granule before it); no slack behind a buffer in either mode
 };

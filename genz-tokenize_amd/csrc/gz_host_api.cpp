@@ -38,7 +38,8 @@ int gz_option_set(GzOptions& o, const char* key, int64_t v)
         {"ph_hot_slots", &GzOptions::ph_hot_slots, nullptr, 0, 8192}, {"word_weights", &GzOptions::word_weights, nullptr, 0, 2},
         {"diag_poison", &GzOptions::diag_poison, nullptr, 0, 1}, {"rows_dpw", &GzOptions::rows_dpw, nullptr, 0, 64},
         {"rows_dbg", &GzOptions::rows_dbg, nullptr, 0, 255}, {"ablate", &GzOptions::ablate, nullptr, 0, 1 << 20},
-        {"diag_guard", &GzOptions::diag_guard, nullptr, 0, 2}, {"host_threads", &GzOptions::host_threads, nullptr, 0, 256},
+        {"diag_guard", &GzOptions::diag_guard, nullptr, 0, 2}, {"diag_exact", &GzOptions::diag_exact, nullptr, 0, 1}, {"diag_fresh", &GzOptions::diag_fresh, nullptr, 0, 256},
+        {"diag_fresh_only", &GzOptions::diag_fresh_only, nullptr, -1, 1 << 20}, {"host_threads", &GzOptions::host_threads, nullptr, 0, 256},
         {"dense_csr", &GzOptions::dense_csr, nullptr, 0, 1}, {"host_hints", &GzOptions::host_hints, nullptr, 0, 3}, {"inject_bad_alloc", &GzOptions::inject_bad_alloc, nullptr, 0, 1 << 30},
     };
     for (const Key& k : keys)

@@ -10,6 +10,7 @@
 #include <condition_variable>
 #include <deque>
 #include <functional>
+#include <map>
 #include <thread>
 #include <sched.h>
 #include <sys/mman.h>
@@ -118,15 +119,25 @@ int pool_threads(gz_ctx* c, size_t bytes_to_move)
     return t <= 1 ? 0 : t;
 }
 
-// Is this host pointer page-locked memory the runtime knows (gz_host_alloc)?  Unknown pointers make the query fail: the error is
-// taken off the runtime's per-thread slot again.
-bool is_pinned(const void* p)
-{
-    if (!p) return false;
-    hipPointerAttribute_t a;
-    if (hipPointerGetAttributes(&a, p) != hipSuccess) { (void)hipGetLastError(); return false; }
-    return a.type == hipMemoryTypeHost;
-}
+// Is this host pointer inside a page-locked block made by gz_host_alloc?  (The library's own registry: asking the runtime about
+// a pointer it has never seen -- any numpy array -- is an error there, and is logged as one.)  Pinned memory from elsewhere is
+// treated like pageable memory: staged, which is always correct.
+struct PinnedRegistry {
+    std::mutex mu;
+    std::map<uintptr_t, size_t> blocks;                          // start -> bytes
+    void add(const void* p, size_t n) { std::lock_guard<std::mutex> lk(mu); blocks[(uintptr_t)p] = n; }
+    void remove(const void* p) { std::lock_guard<std::mutex> lk(mu); blocks.erase((uintptr_t)p); }
+    bool holds(const void* p, size_t n)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        auto it = blocks.upper_bound((uintptr_t)p);
+        if (it == blocks.begin()) return false;
+        --it;
+        return (uintptr_t)p >= it->first && (uintptr_t)p + n <= it->first + it->second;
+    }
+};
+PinnedRegistry& pinned_registry() { static PinnedRegistry r; return r; }
+bool is_pinned(const void* p, size_t bytes = 1) { return p && pinned_registry().holds(p, bytes ? bytes : 1); }
 
 int pinned_need(gz_ctx* c, uint8_t*& p, size_t& cap, size_t bytes)
 {
@@ -160,7 +171,7 @@ int xfer_need(gz_ctx* c, size_t bytes)
 int copy_in(gz_ctx* c, void* dst_dev, const void* src_host, size_t bytes, hipStream_t s)
 {
     if (!bytes) return GZ_OK;
-    if (bytes >= 65536 && is_pinned(src_host)) {
+    if (bytes >= 65536 && is_pinned(src_host, bytes)) {
         HIPCHK(c, hipMemcpyAsync(dst_dev, src_host, bytes, hipMemcpyHostToDevice, s));
         return GZ_OK;
     }
@@ -184,7 +195,7 @@ int copy_in(gz_ctx* c, void* dst_dev, const void* src_host, size_t bytes, hipStr
 int copy_out(gz_ctx* c, void* dst_host, const void* src_dev, size_t bytes, hipStream_t s, HostPool* pool = nullptr)
 {
     if (!bytes) return GZ_OK;
-    if (bytes >= 65536 && is_pinned(dst_host)) {
+    if (bytes >= 65536 && is_pinned(dst_host, bytes)) {
         HIPCHK(c, hipMemcpyAsync(dst_host, src_dev, bytes, hipMemcpyDeviceToHost, s));
         HIPCHK(c, hipStreamSynchronize(s));
         return GZ_OK;

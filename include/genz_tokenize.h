@@ -239,9 +239,12 @@ int64_t gz_limit(int which);
  *   host_threads (0..256; 0)   worker threads of a large host call (0: by the processors this process may use, at most 32)
  *   dense_csr (0..1; 1)        a large dense single-text gz_encode_batch brings only the rows' real entries over the bus and pads them
  *                              into the caller's arrays on the host; 0: the dense rows cross
+ *   host_hints (0..3; 0)       fresh output arrays of a large host call: bit 0 MADV_HUGEPAGE on them, bit 1 MADV_POPULATE_WRITE per piece
  *   inject_bad_alloc (>= 0; 0) test hook: the k-th allocation site reached from now on throws std::bad_alloc (the call answers GZ_E_NOMEM)
  *   diagnostic build only: diag_poison (0..1), rows_dpw, rows_dbg, ablate, diag_guard (0..2: every device buffer its own mapping
- *                              between unmapped granules, no slack -- 1 the buffer ends at its mapping's last byte, 2 it starts at the first)
+ *                              between unmapped granules, no slack -- 1 the buffer ends at its mapping's last byte, 2 it starts at the first),
+ *                              diag_exact (0..1: hipMalloc of exactly the bytes asked for), diag_fresh (0..256: v > 0 fills every fresh
+ *                              allocation with byte v - 1), diag_fresh_only (-1 | k: ... only the k-th allocation of the context)
  * Returns GZ_OK, or GZ_E_INVALID for an unknown key or a value out of range (nothing is changed then). */
 int  gz_debug_set(gz_ctx *ctx, const char *key, int64_t value);
 
