@@ -325,6 +325,77 @@ def test_csr_host_path_matches_dense(tok, sampler, tmp_path):
     assert np.array_equal(i5, d5["input_ids"]) and np.array_equal(m5, d5["attention_mask"])
 
 
+def test_dense_host_path_pads_rows_on_the_host_and_equals_the_device_rows(tok, sampler, tmp_path):
+    """gz_encode_batch, large dense single-text calls (the batch form of tokenize.py:184-259): the rows' real entries come over the bus
+    in sub-batches and are PADDED INTO THE CALLER'S ARRAYS BY HOST THREADS (csr_core, gz_hostpath.h) -- no caller memory is handed to a
+    HIP copy.  Against rows made WITHOUT that machinery: the device entry point's dense rows read back, and the same host call with the
+    switch dense_csr = 0 (dense rows over the bus, staged through the library's pinned buffers).  Several sub-batches; pageable and
+    pinned text; 1, 3 and the default number of worker threads; long rows of short documents (sub-batches cut by ROWS, not by text);
+    a vocabulary whose ids need 32-bit entries; row_off / status / n_real as the header promises them."""
+    from genz_tokenize import Tokenize, _native
+    ctx = tok._ctx
+    text, offs, L = corpus.config_corpus(3, n_docs=300_000, seed=23, sampler=sampler)       # ~86 MB: 3 sub-batches of text
+    text = np.ascontiguousarray(text); offs = np.ascontiguousarray(offs, dtype=np.int64)
+    n = len(offs) - 1
+    # the reference rows: device entry point, rows read back
+    d_t = ctx.alloc(len(text) + 64); ctx.h2d(d_t, text)
+    d_o = ctx.alloc(8 * (n + 1)); ctx.h2d(d_o, offs)
+    d_i, d_m, d_n = ctx.alloc(4 * n * L), ctx.alloc(4 * n * L), ctx.alloc(4 * n)
+    ctx.encode_device(d_t, d_o, 0, 0, n, L, _native.GZ_PADDING | _native.GZ_TRUNCATION, n * L, d_i, d_m, d_n_real=d_n, h_text_off=offs)
+    ctx.sync()
+    want_i = np.empty((n, L), np.int32); want_m = np.empty((n, L), np.int32); want_n = np.empty(n, np.int32)
+    ctx.d2h(want_i, d_i); ctx.d2h(want_m, d_m); ctx.d2h(want_n, d_n)
+    for q in (d_t, d_o, d_i, d_m, d_n):
+        ctx.free(q)
+    assert (want_n == L).any() and (want_n < L).any()                # (rows that were cut, rows that were padded)
+
+    def same(r, what):
+        assert np.array_equal(r["input_ids"].reshape(n, L), want_i), what
+        assert np.array_equal(r["attention_mask"].reshape(n, L), want_m), what
+        assert np.array_equal(r["n_real"], want_n) and not r["status"].any(), what
+        assert np.array_equal(r["row_off"], np.arange(n + 1, dtype=np.int64) * L), what
+
+    same(ctx.encode(text, offs, None, None, L, True, True), "pageable text")
+    ptext = ctx.pinned_empty(len(text), np.uint8); ptext[:] = text
+    same(ctx.encode(ptext, offs, None, None, L, True, True), "pinned text")
+    for thr in (1, 3):
+        _native.debug_set("host_threads", thr, ctx)
+        same(ctx.encode(text, offs, None, None, L, True, True), "host_threads=%d" % thr)
+    _native.debug_set("host_threads", 0, ctx)
+    for hints in (1, 2, 3):
+        _native.debug_set("host_hints", hints, ctx)
+        same(ctx.encode(text, offs, None, None, L, True, True), "host_hints=%d" % hints)
+    _native.debug_set("host_hints", 0, ctx)
+    _native.debug_set("dense_csr", 0, ctx)
+    same(ctx.encode(text, offs, None, None, L, True, True), "dense_csr=0: the dense rows over the bus")
+    _native.debug_set("dense_csr", 1, ctx)
+    same(ctx.encode(text, offs, None, None, L, True, True, _native.GZ_NO_WORD_TABLE), "every word through the merge loop")
+    # long rows of short documents: 120 000 x 1024 entries = 0.98 GB of rows from 14 MB of text -- sub-batches are cut by rows
+    t2, o2, _ = corpus.config_corpus(2, n_docs=120_000, seed=3, sampler=sampler)
+    t2 = np.ascontiguousarray(t2); o2 = np.ascontiguousarray(o2, dtype=np.int64)
+    r2 = ctx.encode(t2, o2, None, None, 1024, True, True)
+    i2, m2 = tok.csr_to_dense(tok.encode_packed_csr(t2, o2, max_len=1024))
+    assert np.array_equal(r2["input_ids"].reshape(-1, 1024), i2) and np.array_equal(r2["attention_mask"].reshape(-1, 1024), m2)
+    import gz_oracle_c as OC
+    co = OC.COracle(open(os.path.join(DATA, "vocab.txt"), "rb").read(), open(os.path.join(DATA, "bpe.codes"), "rb").read())
+    k = 2000
+    wi, wm, _, _, row, _, _ = co.call_packed(t2[:o2[k]], o2[:k + 1], max_len=1024)
+    assert np.array_equal(wi[:int(row[-1])].reshape(k, 1024), r2["input_ids"].reshape(-1, 1024)[:k])
+    assert np.array_equal(wm[:int(row[-1])].reshape(k, 1024), r2["attention_mask"].reshape(-1, 1024)[:k])
+    del r2, i2, m2
+    # ids above 65535: the entries travel as 32-bit words
+    v, b = corpus.custom_tables()
+    (tmp_path / "v").write_bytes(v); (tmp_path / "b").write_bytes(b)
+    t5 = Tokenize.fromFile(str(tmp_path / "v"), str(tmp_path / "b"))
+    text5, offs5, L5 = corpus.config_corpus(5, n_docs=2500, sampler=sampler)                # 13 MB of text, 20 MB of rows: the large path
+    text5 = np.ascontiguousarray(text5); offs5 = np.ascontiguousarray(offs5, dtype=np.int64)
+    a = t5._ctx.encode(text5, offs5, None, None, L5, True, True)
+    _native.debug_set("dense_csr", 0, t5._ctx)
+    b5 = t5._ctx.encode(text5, offs5, None, None, L5, True, True)
+    assert int(a["input_ids"].max()) > 65535
+    assert np.array_equal(a["input_ids"], b5["input_ids"]) and np.array_equal(a["attention_mask"], b5["attention_mask"]) and np.array_equal(a["n_real"], b5["n_real"])
+
+
 def test_big_pipeline_on_small_inputs():
     """Small dense single-text batches run in ONE fused launch (gz_small_kernel); the switch small = 0 sends them through the
     kernel pipeline instead.  The golden vectors and the small-input comparisons of this file run again that way in a

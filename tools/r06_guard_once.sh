@@ -10,7 +10,7 @@ mode=${1:-1}; tag=${2:-g$mode}
 SEL=${3:-"not index_assertions and not scan_time_out and not no_gpu_means and not bench_ and not multirank and not rccl and not table_cache"}
 mkdir -p gpurun_out
 make -C genz-tokenize_amd/csrc diag > gpurun_out/guard_$tag.make 2>&1 || { tail -20 gpurun_out/guard_$tag.make; exit 1; }
-GZ_LIBRARY=$PWD/build_ab/libgz_diag.so GZ_TEST_SWITCHES="diag_guard=$mode" GZ_TABLE_CACHE=off AMD_LOG_LEVEL=1 \
+GZ_LIBRARY=$PWD/build_ab/libgz_diag.so GZ_TEST_SWITCHES="diag_guard=$mode${EXTRA_SWITCHES:+,$EXTRA_SWITCHES}" GZ_TABLE_CACHE=off AMD_LOG_LEVEL=1 \
   timeout -k 10 1000 python -X faulthandler -m pytest tests/test_gpu_parity.py -m gpu -x -q -p no:cacheprovider -k "$SEL" \
   > gpurun_out/guard_$tag.out 2> gpurun_out/guard_$tag.err
 rc=$?
