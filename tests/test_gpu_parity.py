@@ -387,6 +387,7 @@ def test_dense_host_path_pads_rows_on_the_host_and_equals_the_device_rows(tok, s
     v, b = corpus.custom_tables()
     (tmp_path / "v").write_bytes(v); (tmp_path / "b").write_bytes(b)
     t5 = Tokenize.fromFile(str(tmp_path / "v"), str(tmp_path / "b"))
+    t5._sync_tables()
     text5, offs5, L5 = corpus.config_corpus(5, n_docs=2500, sampler=sampler)                # 13 MB of text, 20 MB of rows: the large path
     text5 = np.ascontiguousarray(text5); offs5 = np.ascontiguousarray(offs5, dtype=np.int64)
     a = t5._ctx.encode(text5, offs5, None, None, L5, True, True)
