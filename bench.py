@@ -641,7 +641,7 @@ def main():
         in_b = shards[0]["in_bytes"] if m == 1 else float(np.mean([sh["in_bytes"] for sh in shards]))
         algo = _algo_bytes(in_b, n, L)
         achieved = algo / (k_ms * 1e-3) / 1e9
-        shard_traffic = _pmc_traffic("r05_pmc_traffic_shard.json")
+        shard_traffic = _pmc_traffic("r06_pmc_traffic_shard.json")
         out = {
             "metric": "UTF-8 MB/s tokenized (Tokenize.__call__ hot path: split + BPE + vocab lookup + pad/trunc + mask)",
             "value": round(total_bytes * args.steps / elapsed / 1e6, 2),
@@ -676,10 +676,10 @@ def main():
                          # the text is streamed twice with 16-byte-per-lane loads (classify, words), which FETCH_SIZE counts at half
                          # their bytes on gfx950 (MI355X_MICROARCH.md, HBM): the corrected figure adds the uncounted half of both passes
                          "traffic_corrected": int(shard_traffic["bytes_per_step"] + in_b) if shard_traffic else None,
-                         "traffic_note": ("profiles/r05_pmc_traffic_shard.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over one "
+                         "traffic_note": ("profiles/r06_pmc_traffic_shard.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over one "
                                           "launch on shard 0 (1.25 M documents), same kernel sources (sha %s); reads of 16-B streams are "
                                           "half-counted on gfx950, not corrected" % kernel_source_sha16()) if shard_traffic else
-                                         "null: profiles/r05_pmc_traffic_shard.json is absent or was taken on other kernel sources",
+                                         "null: profiles/r06_pmc_traffic_shard.json is absent or was taken on other kernel sources",
                          "algorithmic_bytes_per_launch": int(algo),
                          "kernel_ms_avg": round(k_ms, 4), "launches_timed": len(kernel_ms),
                          "timed_with": "hipEvents on the library's stream around each launch of the pipeline, inside the timed region"},
@@ -780,7 +780,7 @@ def secondary(ctx, tok, flags, args, cfg2):
     n_tok = int(mask.sum(dtype=np.int64))
     del ids, mask
     algo = _algo_bytes(R.in_bytes, R.n, L)
-    traffic = _pmc_traffic("r05_pmc_traffic.json")
+    traffic = _pmc_traffic("r06_pmc_traffic.json")
     # (ii) device end-to-end: host buffers in, host buffers out (PCIe both ways).  The library's host path for batches is
     # gz_encode_batch_csr: sub-batches, text H2D / kernels / D2H on three streams, and only the rows' real entries
     # (16-bit) + 4 bytes per document come back; the buffers are pinned (gz_host_alloc), as SURVEY.md 8(d) (ii) says.
@@ -842,9 +842,9 @@ def secondary(ctx, tok, flags, args, cfg2):
                      "frac": round(algo / k_ms / 1e6 / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_launch": int(algo),
                      "kernel_ms_avg": round(k_ms, 4),
                      "traffic": traffic["bytes_per_step"] if traffic else None,
-                     "traffic_source": "profiles/r05_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, summed over the "
+                     "traffic_source": "profiles/r06_pmc_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, summed over the "
                                        "launch's kernels; reads not corrected for the gfx950 half-count)" if traffic else
-                                       "none for this build (profiles/r05_pmc_traffic.json absent or taken on other kernel sources)"}}
+                                       "none for this build (profiles/r06_pmc_traffic.json absent or taken on other kernel sources)"}}
     # ---- the same documents WITHOUT padding (max_len=None, the reference's default call: ragged rows + int64 row offsets): all kernels
     # of the call by hipEvents, inputs / outputs resident
     capu = R.in_bytes + 2 * R.n
@@ -965,7 +965,7 @@ def secondary(ctx, tok, flags, args, cfg2):
             sys.exit("bench: " + e5)
         v5 = "C-oracle sha256 over all %d documents (tests/golden/g5_hashes.json cfg5_50k; its first 300 documents also hashed by the reference): match" % R5.n
     a5 = _algo_bytes(R5.in_bytes, R5.n, L5)
-    t5j = _pmc_traffic("r05_pmc_traffic_cfg4.json")
+    t5j = _pmc_traffic("r06_pmc_traffic_cfg4.json")
     # ... and the unpadded run SURVEY.md 8(d) asks for beside it (max_len=None: ragged rows + row offsets; parity: the suite's
     # test_cfg5_full_size_padded_and_unpadded): kernels by hipEvents, inputs / outputs resident
     c5 = tok5._ctx
@@ -996,8 +996,8 @@ def secondary(ctx, tok, flags, args, cfg2):
         "roofline": {"bound": "hbm", "achieved": round(a5 / k5 / 1e6, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": round(a5 / k5 / 1e6 / HBM_PEAK_GBS, 5), "algorithmic_bytes_per_launch": int(a5),
                      "traffic": t5j["bytes_per_step"] if t5j else None,
-                     "traffic_source": "profiles/r05_pmc_traffic_cfg4.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/prof_cfg5.py)"
-                                       if t5j else "none for this build (profiles/r05_pmc_traffic_cfg4.json absent or taken on other kernel sources)"}}
+                     "traffic_source": "profiles/r06_pmc_traffic_cfg4.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, tools/prof_cfg5.py)"
+                                       if t5j else "none for this build (profiles/r06_pmc_traffic_cfg4.json absent or taken on other kernel sources)"}}
     R5.free()
     return out
 

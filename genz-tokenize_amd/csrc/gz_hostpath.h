@@ -51,7 +51,14 @@ class HostPool {
 public:
     explicit HostPool(int n_threads)
     {
-        for (int i = 0; i < n_threads; ++i) th_.emplace_back([this] { run(); });
+        // (a thread that cannot be made -- a process at its limit -- is simply not there: the call runs with the ones it got, or on
+        //  the caller's thread.  Nothing may escape this constructor once a thread runs: the vector's destructor would meet a
+        //  joinable thread, which is std::terminate)
+        try {
+            th_.reserve((size_t)(n_threads > 0 ? n_threads : 0));
+            for (int i = 0; i < n_threads; ++i) th_.emplace_back([this] { run(); });
+        } catch (...) {
+        }
     }
     ~HostPool()
     {

@@ -2,7 +2,7 @@
 # usage (build container, repo root): tools/copy_final.sh <tag> [round, default r05]   -- gpurun_out/final_<tag>/* (tools/final_set.sh) -> profiles/<round>_*
 set -e
 O=gpurun_out/final_$1
-ROUND=${2:-r05}
+ROUND=${2:-r06}
 cp $O/bench.json.log profiles/${ROUND}_bench.json.log
 cp $O/bench_kernel_stats.csv profiles/${ROUND}_bench_kernel_stats.csv
 cp $O/bench_steady_state.txt profiles/${ROUND}_bench_steady_state.txt

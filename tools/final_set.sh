@@ -7,7 +7,7 @@
 #   (7) the default bench line.
 set -o pipefail
 tag=$1
-ROUND=${2:-r05}
+ROUND=${2:-r06}
 R=$PWD
 O=$R/gpurun_out/final_$tag
 mkdir -p $O
