@@ -121,6 +121,7 @@ static PyObject* gz_pack_into(PyObject* self, PyObject* args)
         int64_t* off = (int64_t*)offb.buf;
         for (; got < n; ++got) {
             PyObject* s = items[got];
+            if (got + 16 < n) __builtin_prefetch(items[got + 16]);      /* (a million str headers scattered over the heap: each one is a cache miss) */
             if (!PyUnicode_Check(s)) { PyErr_SetString(PyExc_TypeError, "expected string or bytes-like object"); break; }
             if (PyUnicode_READY(s) < 0) break;
             Py_INCREF(s);
@@ -145,7 +146,7 @@ static PyObject* gz_pack_into(PyObject* self, PyObject* args)
             result = PyLong_FromLongLong(fits ? (long long)off[n] : -(long long)off[n]);
         }
     }
-    for (Py_ssize_t i = 0; i < got; ++i) Py_DECREF(held[i]);
+    for (Py_ssize_t i = 0; i < got; ++i) { if (i + 16 < got) __builtin_prefetch(held[i + 16], 1); Py_DECREF(held[i]); }
     free(it); free(held);
     Py_DECREF(seq);
     PyBuffer_Release(&outb); PyBuffer_Release(&offb);
@@ -168,6 +169,7 @@ static PyObject* gz_pack(PyObject* self, PyObject* arg)
     Py_ssize_t got = 0;
     for (; got < n; ++got) {
         PyObject* s = items[got];
+        if (got + 16 < n) __builtin_prefetch(items[got + 16]);
         if (!PyUnicode_Check(s)) { PyErr_SetString(PyExc_TypeError, "expected string or bytes-like object"); break; }
         if (PyUnicode_READY(s) < 0) break;
         Py_INCREF(s);
@@ -193,7 +195,7 @@ static PyObject* gz_pack(PyObject* self, PyObject* arg)
             Py_END_ALLOW_THREADS
         }
     }
-    for (Py_ssize_t i = 0; i < got; ++i) Py_DECREF(held[i]);
+    for (Py_ssize_t i = 0; i < got; ++i) { if (i + 16 < got) __builtin_prefetch(held[i + 16], 1); Py_DECREF(held[i]); }
     free(it); free(held);
     Py_DECREF(seq);
     if (!text) { Py_DECREF(offs); return NULL; }
