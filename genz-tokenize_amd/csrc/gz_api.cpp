@@ -1384,7 +1384,9 @@ static int csr_core(gz_ctx* c, const uint8_t* text, const int64_t* text_off, int
     const int32_t pad_id = c->dev.pad_id;
     int64_t total = 0;
     int ret = GZ_OK;
-    const int LAG = 2;                                           // sub-batches enqueued ahead of the one whose rows the host takes
+    // sub-batches enqueued ahead of the one whose rows the host takes: everything when the text is pinned (every copy-in is queued at
+    // once: the bus never waits for the host), two when it goes through the two pinned text buffers
+    const int LAG = text_direct ? nsub : 2;
     for (int step = 0; step < nsub + LAG; ++step) {
         if (step < nsub) {
             // ---- sub-batch k: text in, kernels
