@@ -1365,7 +1365,8 @@ static int csr_core(gz_ctx* c, const uint8_t* text, const int64_t* text_off, int
     if (!text_direct)
         for (int q = 0; q < (nsub > 1 ? 2 : 1); ++q)
             if ((rc = pinned_need(c, c->h_tin[q], c->h_tin_cap[q], (size_t)bmax + 16))) return rc;
-    HostPool pool(pool_threads(c, dense_out ? (size_t)n_docs * (size_t)max_len * 8 : (size_t)tb));
+    // (worker threads only when something has to be moved by the host: pinned text in and pinned CSR rows out need none)
+    HostPool pool((text_direct && out_direct) ? 0 : pool_threads(c, dense_out ? (size_t)n_docs * (size_t)max_len * 8 : (size_t)tb));
     alloc_site(c);
     std::vector<uint32_t> row_first[3];                          // dense form: where each row of the slot's sub-batch starts among its entries
     if (dense_out) {
