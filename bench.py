@@ -796,7 +796,7 @@ def secondary(ctx, tok, flags, args, cfg2):
     csr_bytes = int(toks.nbytes + nr.nbytes)
     # ... and what the same call costs when the caller wants the dense [N, L] int32 arrays in pageable host memory
     e2e_dense = []
-    for _ in range(2):
+    for _ in range(3):                       # (the first call also makes the library's pinned staging buffers; the host's 2 GB of first-touch stores vary by box)
         t_a = time.perf_counter()
         r = ctx.encode(text, offs, None, None, L, True, True)
         e2e_dense.append(time.perf_counter() - t_a)
@@ -829,7 +829,7 @@ def secondary(ctx, tok, flags, args, cfg2):
         "verified": "reference sha256 (tests/golden/g5_hashes.json cfg3_1M, computed by the reference itself): match",
         "timings": {"kernels_ms": round(k_ms, 4), "device_e2e_ms": round(min(e2e) * 1e3, 3), "python_e2e_ms": round(py_e2e * 1e3, 2), "python_e2e_ms_runs": [round(x * 1e3, 2) for x in py_runs],
                     "python_to_device_ms": round(min(py_dev) * 1e3, 2),
-                    "device_e2e_dense_pageable_ms": round(min(e2e_dense) * 1e3, 2), "device_e2e_bytes_over_pcie": int(R.in_bytes + 8 * (R.n + 1) + csr_bytes),
+                    "device_e2e_dense_pageable_ms": round(min(e2e_dense) * 1e3, 2), "device_e2e_dense_pageable_ms_runs": [round(x * 1e3, 2) for x in e2e_dense], "device_e2e_bytes_over_pcie": int(R.in_bytes + 8 * (R.n + 1) + csr_bytes),
                     "MB_per_s": {"kernels": round(R.in_bytes / k_ms / 1e3, 1), "device_e2e": round(R.in_bytes / min(e2e) / 1e6, 1), "device_e2e_dense_pageable": round(R.in_bytes / min(e2e_dense) / 1e6, 1),
                                  "python_e2e": round(R.in_bytes / py_e2e / 1e6, 1), "python_to_device": round(R.in_bytes / min(py_dev) / 1e6, 1)},
                     "what": "(i) hipEvents around the launches, inputs/outputs in HBM; (ii) gz_encode_batch_csr on pinned host buffers: "
