@@ -70,8 +70,6 @@ struct GzOptions {
     int32_t hot_miss_wgs = 0;         // grid of gz_miss2_kernel (0: as above)
     int64_t m2_split_min = 65536;     // chunks of misses from which the merge kernel's two instances share a launch (0: never)
     int32_t m2_split_always = 0;      // 1: ... also with the whole-word tables on
-    int32_t rows_ws = 1;              // dense rows of single texts, max_len <= 256: 0 gz_rows1_kernel always; 1 gz_rows1ws_kernel (loads and stores of a
-                                      // round in different waves) from 65 536 documents on; 2 always
     // ---- builder (process-wide: read when tables are built)
     int32_t tab_slack = GZ_TAB_SLACK; // long-key whole-word table: slots >= this x entries (2 .. 64)
     int32_t ph_force_overflow = 0;    // k > 0: the perfect-hash builder refuses every k-th bucket (overflow paths of the kernels)

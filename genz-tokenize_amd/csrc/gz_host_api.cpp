@@ -33,7 +33,7 @@ int gz_option_set(GzOptions& o, const char* key, int64_t v)
         {"brk_side", &GzOptions::brk_side, nullptr, 0, 1}, {"scan_multi", nullptr, &GzOptions::scan_multi, 0, (int64_t)1 << 40},
         {"near_limit", nullptr, &GzOptions::near_limit, 0, 1 << 25}, {"hot_wgs", &GzOptions::hot_wgs, nullptr, 0, 1 << 16},
         {"hot_miss_wgs", &GzOptions::hot_miss_wgs, nullptr, 0, 1 << 16}, {"m2_split_min", nullptr, &GzOptions::m2_split_min, 0, (int64_t)1 << 32},
-        {"m2_split_always", &GzOptions::m2_split_always, nullptr, 0, 1}, {"rows_ws", &GzOptions::rows_ws, nullptr, 0, 2},
+        {"m2_split_always", &GzOptions::m2_split_always, nullptr, 0, 1},
         {"tab_slack", &GzOptions::tab_slack, nullptr, 2, 64}, {"ph_force_overflow", &GzOptions::ph_force_overflow, nullptr, 0, 1 << 20},
         {"ph_hot_slots", &GzOptions::ph_hot_slots, nullptr, 0, 8192}, {"word_weights", &GzOptions::word_weights, nullptr, 0, 2},
         {"diag_poison", &GzOptions::diag_poison, nullptr, 0, 1}, {"rows_dpw", &GzOptions::rows_dpw, nullptr, 0, 64},

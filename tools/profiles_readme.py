@@ -17,6 +17,11 @@ EXACT = {
     "r06_merge_id_phase_ab.txt": "`tools/r06_ids_ab.sh`: the merge kernel's id loads all before the stores vs the build before, traced, alternating, three workloads: nothing outside the box band; not kept",
     "r06_phase_stamps.txt": "`tools/prof_diag.py` on the diagnostic build: cycles per phase of `gz_miss2_kernel` (tables on / off) and of a round of `gz_rows1_kernel` (one wave in 61 reporting; with and without the wait for the stores)",
     "r06_rows1_docs_per_wave.txt": "timing build, switch `rows_dpw`: 4 / 8 / 16 / 24 documents per wave of the row kernel, alternating: 8 (one round per wave) stays best",
+    "r06_rows1_what_bounds_it.txt": "`tools/r06_rows_probe.sh` on the timing build: the row kernel with stores only / loads + walk only / ids only / more documents per wave, and the plain fill (`tools/membw`) on the same box",
+    "r06_rows1_waves_per_workgroup.txt": "build parameter `GZ_ROWS_WPB` = 1 / 2 / 4 / 8 waves per workgroup of the row kernel, traced, alternating: 4 stays",
+    "r06_rows_ws_ab.txt": "`tools/r06_ws.sh` (commit d395452): the row kernel with producer and consumer waves against `gz_rows1_kernel`, four batch sizes, alternating: slower everywhere",
+    "r06_rows_ws_probe.txt": "`tools/r06_ws_probe.sh`, first form (7 producers + 1 consumer): each side alone -- the consumer side is the slow one",
+    "r06_rows_ws_probe_v2.txt": "... second form (6 + 2, no store in a producer, indices one group ahead): each side near the old kernel's, together nearly the sum",
     "r06_size_exchange_gloo.txt": "the exchange step's size exchange (one gloo all-gather of an int64) ON THE GPU BOX'S HOST: 85 us at world 2, 506 us at world 8",
     "r05_size_exchange_gloo.txt": "the same test in the BUILD CONTAINER (8 cores): 465 us at world 2, 1 932 us at world 8 -- a figure of that container, not of a node",
 }

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the kernel and its switch rows_ws exist in commits d395452 and 43d6d23 only: the experiment lost, see profiles/r06_ab_variants.txt series 6 -- check one of them out to run this)
 # usage (GPU box, repo root): tools/r06_ws.sh <tag>  -- gz_rows1ws_kernel (loads and stores of a round in different waves): parity with the switch forced on
 # for every batch size, then the launch time against gz_rows1_kernel, alternating on this box (product build, switch rows_ws)
 set -o pipefail

@@ -1,4 +1,5 @@
 #!/bin/bash
+# (the kernel and its switch rows_ws exist in commits d395452 and 43d6d23 only: the experiment lost, see profiles/r06_ab_variants.txt series 6 -- check one of them out to run this)
 # usage (GPU box, repo root): tools/r06_ws_probe.sh <tag>  -- timing build: which side bounds gz_rows1ws_kernel?  (whole-launch times; the text side is constant)
 set -o pipefail
 tag=${1:-x}
