@@ -800,8 +800,9 @@ def secondary(ctx, tok, flags, args, cfg2):
         t_a = time.perf_counter()
         r = ctx.encode(text, offs, None, None, L, True, True)
         e2e_dense.append(time.perf_counter() - t_a)
-    ok_e2e = ok_e2e and int(r["attention_mask"].sum(dtype=np.int64)) == n_tok
-    del r, toks, nr, ptext, ptok, pnr
+        ok_e2e = ok_e2e and int(r["attention_mask"].sum(dtype=np.int64)) == n_tok
+        del r                                # (outside the clock: giving 2 GB of arrays back to the system takes as long as the call)
+    del toks, nr, ptext, ptok, pnr
     # (iii) Python end-to-end: list of str in (packing included), numpy arrays out
     raw = text.tobytes()
     docs = [raw[offs[i]:offs[i + 1]].decode("utf-8") for i in range(R.n)]
