@@ -19,6 +19,7 @@ EXACT = {
     "r06_rows1_docs_per_wave.txt": "timing build, switch `rows_dpw`: 4 / 8 / 16 / 24 documents per wave of the row kernel, alternating: 8 (one round per wave) stays best",
     "r06_rows1_what_bounds_it.txt": "`tools/r06_rows_probe.sh` on the timing build: the row kernel with stores only / loads + walk only / ids only / more documents per wave, and the plain fill (`tools/membw`) on the same box",
     "r06_rows1_waves_per_workgroup.txt": "build parameter `GZ_ROWS_WPB` = 1 / 2 / 4 / 8 waves per workgroup of the row kernel, traced, alternating: 4 stays",
+    "r06_rows1_scalar_first_indices_ab.txt": "the row kernel's first-word indices by scalar loads (s_load_dword) instead of one vector load, traced, three alternations: 2-3 % slower; not kept",
     "r06_rows_ws_ab.txt": "`tools/r06_ws.sh` (commit d395452): the row kernel with producer and consumer waves against `gz_rows1_kernel`, four batch sizes, alternating: slower everywhere",
     "r06_rows_ws_probe.txt": "`tools/r06_ws_probe.sh`, first form (7 producers + 1 consumer): each side alone -- the consumer side is the slow one",
     "r06_rows_ws_probe_v2.txt": "... second form (6 + 2, no store in a producer, indices one group ahead): each side near the old kernel's, together nearly the sum",
