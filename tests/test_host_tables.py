@@ -236,3 +236,24 @@ def test_allocation_failure_in_the_host_builder_is_an_error_code(tmp_path):
     r = subprocess.run([exe, os.path.join(DATA, "vocab.txt"), os.path.join(DATA, "bpe.codes"), "997"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, "rc %d\n%s\n%s" % (r.returncode, r.stdout[-2000:], r.stderr[-2000:])
     assert "other: 0" in r.stdout and "GZ_E_NOMEM" in r.stdout
+
+
+@pytest.mark.parametrize("sanitizer", ["thread", "address,undefined"])
+def test_host_pool_and_row_expansion_under_sanitizers(tmp_path, sanitizer):
+    """The HIP-free part of the library's host paths (csrc/gz_hostpool.h: the worker threads of a large host call, the padding of CSR
+    rows into the caller's dense arrays, the registry of pinned blocks) built alone with -fsanitize=thread and with
+    -fsanitize=address,undefined (tests/native/hostpool_main.cpp): rows padded through the pool the way csr_core uses it -- rotating
+    slots, tagged jobs -- equal a restatement of tokenize.py:141-152 for 0 / 1 / 5 threads and both entry widths; the pool's queue,
+    parallel(), and its destruction with jobs still queued; the registry under concurrent use.  Any report fails the test."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    exe = str(tmp_path / "hostpool")
+    c = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=" + sanitizer, "-fno-sanitize-recover=undefined",
+                        os.path.join(ROOT, "tests", "native", "hostpool_main.cpp"), "-o", exe, "-lpthread"], capture_output=True, text=True, timeout=600)
+    if c.returncode != 0 and "cannot find" in (c.stderr or "") and "san" in c.stderr:
+        pytest.skip("sanitizer runtime not installed")
+    assert c.returncode == 0, c.stderr[-3000:]
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=600, env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1:exitcode=66"))
+    assert r.returncode == 0 and "host pool driver ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "Sanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-4000:]
