@@ -1380,32 +1380,42 @@ static int csr_core(gz_ctx* c, const uint8_t* text, const int64_t* text_off, int
     // finish what is queued and are joined (its destructor)
     struct Drain { gz_ctx* c; ~Drain() { hipStreamSynchronize(c->s_in); hipStreamSynchronize(c->stream); hipStreamSynchronize(c->s_out); } } drain{c};
 
-    if ((rc = copy_in(c, c->w_toff.p, text_off, (size_t)(n_docs + 1) * 8, c->s_in))) return rc;
+    // sub-batch k's text onto the copy-in stream (ev_in[k] behind it)
+    auto text_in = [&](int k) -> int {
+        const int64_t lo = lo_of(k), hi = lo_of(k + 1);
+        const int64_t b0 = text_off[lo], b1 = text_off[hi];
+        if (b1 > b0) {
+            uint8_t* dst = (uint8_t*)c->w_text.p + (b0 - text_off[0]);
+            if (text_direct) HIPCHK(c, hipMemcpyAsync(dst, text + b0, (size_t)(b1 - b0), hipMemcpyHostToDevice, c->s_in));
+            else {
+                uint8_t* h = c->h_tin[k & 1];
+                if (k >= 2) HIPCHK(c, hipEventSynchronize(c->ev_in[k - 2]));        // (the copy that last read this buffer)
+                const uint8_t* src = text + b0;
+                pool.parallel((size_t)(b1 - b0), (size_t)1 << 20, [=](size_t a, size_t b) { std::memcpy(h + a, src + a, b - a); });
+                HIPCHK(c, hipMemcpyAsync(dst, h, (size_t)(b1 - b0), hipMemcpyHostToDevice, c->s_in));
+            }
+        }
+        HIPCHK(c, hipEventRecord(c->ev_in[k], c->s_in));
+        return GZ_OK;
+    };
+    // Pinned text: EVERY copy-in is queued before anything else -- the bus never waits for the host.  The offsets -- 8 bytes per
+    // document, pageable as a rule: staged piece by piece -- go on the MAIN stream, in front of the kernels that read them, while the first
+    // sub-batch's text is already on its way.
+    if (text_direct) for (int k = 0; k < nsub; ++k) if ((rc = text_in(k))) return rc;
+    if ((rc = copy_in(c, c->w_toff.p, text_off, (size_t)(n_docs + 1) * 8, s))) return rc;
     HIPCHK(c, hipMemsetAsync(c->w_flags.p, 0, 16, s));
     const int32_t pad_id = c->dev.pad_id;
     int64_t total = 0;
     int ret = GZ_OK;
-    // sub-batches enqueued ahead of the one whose rows the host takes: everything when the text is pinned (every copy-in is queued at
-    // once: the bus never waits for the host), two when it goes through the two pinned text buffers
+    // sub-batches whose kernels are enqueued ahead of the one whose rows the host takes: all of them when the text is pinned, two when it
+    // goes through the two pinned text buffers
     const int LAG = text_direct ? nsub : 2;
     for (int step = 0; step < nsub + LAG; ++step) {
         if (step < nsub) {
-            // ---- sub-batch k: text in, kernels
+            // ---- sub-batch k: text in (unless it is on its way already), kernels
             const int k = step;
             const int64_t lo = lo_of(k), hi = lo_of(k + 1);
-            const int64_t b0 = text_off[lo], b1 = text_off[hi];
-            if (b1 > b0) {
-                uint8_t* dst = (uint8_t*)c->w_text.p + (b0 - text_off[0]);
-                if (text_direct) HIPCHK(c, hipMemcpyAsync(dst, text + b0, (size_t)(b1 - b0), hipMemcpyHostToDevice, c->s_in));
-                else {
-                    uint8_t* h = c->h_tin[k & 1];
-                    if (k >= 2) HIPCHK(c, hipEventSynchronize(c->ev_in[k - 2]));        // (the copy that last read this buffer)
-                    const uint8_t* src = text + b0;
-                    pool.parallel((size_t)(b1 - b0), (size_t)1 << 20, [=](size_t a, size_t b) { std::memcpy(h + a, src + a, b - a); });
-                    HIPCHK(c, hipMemcpyAsync(dst, h, (size_t)(b1 - b0), hipMemcpyHostToDevice, c->s_in));
-                }
-            }
-            HIPCHK(c, hipEventRecord(c->ev_in[k], c->s_in));
+            if (!text_direct && (rc = text_in(k))) return rc;
             GzAsmArgs A{};
             A.n_texts = 1; A.n_docs = hi - lo; A.dense = 1; A.max_len = max_len;
             A.ids = (int32_t*)c->w_csr_ids[k & 1].p; A.mask = (int32_t*)c->w_csr_mask[k & 1].p;
