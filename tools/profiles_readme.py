@@ -23,6 +23,7 @@ EXACT = {
     "r06_rows_ws_ab.txt": "`tools/r06_ws.sh` (commit d395452): the row kernel with producer and consumer waves against `gz_rows1_kernel`, four batch sizes, alternating: slower everywhere",
     "r06_rows_ws_probe.txt": "`tools/r06_ws_probe.sh`, first form (7 producers + 1 consumer): each side alone -- the consumer side is the slow one",
     "r06_rows_ws_probe_v2.txt": "... second form (6 + 2, no store in a producer, indices one group ahead): each side near the old kernel's, together nearly the sum",
+    "r06_side_stream_tail_variants.txt": "launcher variants of the side stream's tail (no `gz_long_kernel`, wide kernel on 1 024 / 4 096 workgroups, without its LDS table copy), traced, alternating: nothing outside the spread",
     "r06_size_exchange_gloo.txt": "the exchange step's size exchange (one gloo all-gather of an int64) ON THE GPU BOX'S HOST: 85 us at world 2, 506 us at world 8",
     "r05_size_exchange_gloo.txt": "the same test in the BUILD CONTAINER (8 cores): 465 us at world 2, 1 932 us at world 8 -- a figure of that container, not of a node",
 }
