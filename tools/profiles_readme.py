@@ -10,6 +10,7 @@ EXACT = {
     "r06_guard_granule_runs.txt": "diagnostic build, guard-granule allocator (`tools/r06_guard_once.sh`): whole GPU suite in mode 1 and mode 2, pipeline / merge-kernel selections: every run green, no fault",
     "r06_guard_address_reuse.txt": "`tools/r06_fresh_bisect.py`: golden single calls under hipMalloc with filled / exact allocations (right) and under the guard allocator with and without address reuse: wrong rows only when a freed range is handed out again",
     "r06_vmm_interior_copies.txt": "`tools/micro/vmm_copy.hip`: H2D / D2D / D2H copies and memsets at interior pointers of virtual-memory mappings: all right (the guard allocator's wrong rows were address reuse, not this)",
+    "r06_docw0_behind_word_kernel.txt": "launcher variant: `gz_docw0_kernel` behind the word kernel instead of beside it (where a self-classifying word kernel would need it), traced, three alternations: text side + 10 us on average",
     "r06_encode_batch_breakdown.txt": "`tools/t_encode_batch.py`, 1 M documents: `encode_batch(list of str)` 70-115 ms = packing 51-53 + `gz_encode_batch` 23-31; by threads, by hints, `dense_csr=0` 92 ms",
     "r06_host_first_touch.txt": "`tools/micro/hostfill.c` on the GPU box's host: first-touch rate of a fresh 2 GiB mapping by 1-32 threads, plain / MADV_HUGEPAGE / MADV_POPULATE_WRITE",
     "r06_fused_classify_ceiling.txt": "`tools/r06_fused_classify_try.py` on the timing build: a word kernel that classifies its own tiles (no classification kernel, no scan, counts for free): 37 us of a 1.29 ms launch; rows equal",
